@@ -1,0 +1,340 @@
+// PyTorch-facing glue for the gfx950 kernels in csrc/kernels.
+//
+// Each function validates shapes / dtypes / alignment on the host (a kernel
+// that reads out of bounds can take the whole node down, so nothing is
+// launched on operands the kernels were not written for), allocates outputs
+// through the caching allocator, and launches on the current HIP stream.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <optional>
+#include <vector>
+
+#include "kernels/pda_kernels.h"
+
+namespace py = pybind11;
+
+namespace {
+
+pda::DType dtype_of(const at::Tensor& t) {
+  if (t.scalar_type() == at::kBFloat16) return pda::kBF16;
+  TORCH_CHECK(t.scalar_type() == at::kFloat, "expected a float32 or bfloat16 tensor, got ", t.scalar_type());
+  return pda::kF32;
+}
+
+void check_gpu(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.defined(), name, " is undefined");
+  TORCH_CHECK(t.is_cuda(), name, " must live on the GPU");
+  TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, " must be 16-byte aligned");
+}
+
+hipStream_t current_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+void check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  TORCH_CHECK(err == hipSuccess, what, " launch failed: ", hipGetErrorString(err));
+}
+
+// ------------------------------------------------------------------ norms --
+std::vector<at::Tensor> norm_forward(const at::Tensor& x, const std::optional<at::Tensor>& residual,
+                                     const at::Tensor& weight, const std::optional<at::Tensor>& bias,
+                                     double eps, bool rms) {
+  check_gpu(x, "x");
+  check_gpu(weight, "weight");
+  const c10::hip::HIPGuard guard(x.device());
+  const int64_t d = x.size(-1);
+  const int64_t rows = x.numel() / d;
+  const auto dt = dtype_of(x);
+  const int vec = dt == pda::kBF16 ? 8 : 4;
+  TORCH_CHECK(d % vec == 0 && d <= 64 * 16 * vec, "norm: unsupported row length ", d);
+  TORCH_CHECK(weight.numel() == d && weight.scalar_type() == x.scalar_type(), "norm: bad weight");
+  const void* bias_ptr = nullptr;
+  if (!rms) {
+    TORCH_CHECK(bias.has_value(), "layernorm needs a bias");
+    check_gpu(*bias, "bias");
+    TORCH_CHECK(bias->numel() == d && bias->scalar_type() == x.scalar_type(), "norm: bad bias");
+    bias_ptr = bias->data_ptr();
+  }
+  const void* res_ptr = nullptr;
+  at::Tensor sum_out;
+  if (residual.has_value()) {
+    check_gpu(*residual, "residual");
+    TORCH_CHECK(residual->sizes() == x.sizes() && residual->scalar_type() == x.scalar_type(),
+                "norm: residual must match x");
+    res_ptr = residual->data_ptr();
+    sum_out = at::empty_like(x);
+  }
+  at::Tensor y = at::empty_like(x);
+  auto stat_opts = x.options().dtype(at::kFloat);
+  at::Tensor rstd = at::empty({rows}, stat_opts);
+  at::Tensor mean = rms ? at::Tensor() : at::empty({rows}, stat_opts);
+  pda::norm_forward(dt, rms, x.data_ptr(), res_ptr, weight.data_ptr(), bias_ptr, y.data_ptr(),
+                    sum_out.defined() ? sum_out.data_ptr() : nullptr,
+                    rms ? nullptr : mean.data_ptr<float>(), rstd.data_ptr<float>(), rows, (int)d,
+                    (float)eps, current_stream());
+  check_launch("norm_forward");
+  return {y, sum_out, mean, rstd};
+}
+
+std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
+                                      const at::Tensor& weight, const std::optional<at::Tensor>& mean,
+                                      const at::Tensor& rstd, const std::optional<at::Tensor>& dresidual,
+                                      bool rms) {
+  check_gpu(dy, "dy");
+  check_gpu(x, "x");
+  check_gpu(weight, "weight");
+  check_gpu(rstd, "rstd");
+  const c10::hip::HIPGuard guard(x.device());
+  const int64_t d = x.size(-1);
+  const int64_t rows = x.numel() / d;
+  const auto dt = dtype_of(x);
+  const int vec = dt == pda::kBF16 ? 8 : 4;
+  TORCH_CHECK(d % vec == 0 && d <= 64 * 16 * vec, "norm: unsupported row length ", d);
+  TORCH_CHECK(dy.sizes() == x.sizes() && dy.scalar_type() == x.scalar_type(), "norm: dy must match x");
+  TORCH_CHECK(weight.numel() == d && weight.scalar_type() == x.scalar_type(), "norm: bad weight");
+  TORCH_CHECK(rstd.numel() == rows && rstd.scalar_type() == at::kFloat, "norm: bad rstd");
+  const float* mean_ptr = nullptr;
+  if (!rms) {
+    TORCH_CHECK(mean.has_value() && mean->defined(), "layernorm backward needs mean");
+    check_gpu(*mean, "mean");
+    TORCH_CHECK(mean->numel() == rows && mean->scalar_type() == at::kFloat, "norm: bad mean");
+    mean_ptr = mean->data_ptr<float>();
+  }
+  const void* dres_ptr = nullptr;
+  if (dresidual.has_value() && dresidual->defined()) {
+    check_gpu(*dresidual, "dresidual");
+    TORCH_CHECK(dresidual->sizes() == x.sizes() && dresidual->scalar_type() == x.scalar_type(),
+                "norm: dresidual must match x");
+    dres_ptr = dresidual->data_ptr();
+  }
+  at::Tensor dx = at::empty_like(x);
+  const int prow = pda::norm_backward_partial_rows(rows);
+  auto f32 = x.options().dtype(at::kFloat);
+  at::Tensor dwp = at::empty({prow, d}, f32);
+  at::Tensor dbp = rms ? at::Tensor() : at::empty({prow, d}, f32);
+  hipStream_t stream = current_stream();
+  pda::norm_backward(dt, rms, dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean_ptr,
+                     rstd.data_ptr<float>(), dres_ptr, dx.data_ptr(), dwp.data_ptr<float>(),
+                     rms ? nullptr : dbp.data_ptr<float>(), rows, (int)d, stream);
+  check_launch("norm_backward");
+  at::Tensor dw = at::empty_like(weight);
+  at::Tensor db = rms ? at::Tensor() : at::empty_like(weight);
+  pda::norm_reduce_partials(dwp.data_ptr<float>(), rms ? nullptr : dbp.data_ptr<float>(), prow, (int)d,
+                            dt, dw.data_ptr(), rms ? nullptr : db.data_ptr(), false, stream);
+  check_launch("norm_reduce_partials");
+  return {dx, dw, db};
+}
+
+// ------------------------------------------------------------ activations --
+at::Tensor gelu_forward(const at::Tensor& u) {
+  check_gpu(u, "u");
+  const c10::hip::HIPGuard guard(u.device());
+  at::Tensor y = at::empty_like(u);
+  pda::gelu_forward(dtype_of(u), u.data_ptr(), y.data_ptr(), u.numel(), current_stream());
+  check_launch("gelu_forward");
+  return y;
+}
+
+at::Tensor gelu_backward(const at::Tensor& dy, const at::Tensor& u) {
+  check_gpu(dy, "dy");
+  check_gpu(u, "u");
+  TORCH_CHECK(dy.sizes() == u.sizes() && dy.scalar_type() == u.scalar_type(), "gelu: dy must match u");
+  const c10::hip::HIPGuard guard(u.device());
+  at::Tensor du = at::empty_like(u);
+  pda::gelu_backward(dtype_of(u), dy.data_ptr(), u.data_ptr(), du.data_ptr(), u.numel(), current_stream());
+  check_launch("gelu_backward");
+  return du;
+}
+
+at::Tensor swiglu_forward(const at::Tensor& x) {
+  check_gpu(x, "x");
+  const c10::hip::HIPGuard guard(x.device());
+  const int64_t f2 = x.size(-1);
+  const auto dt = dtype_of(x);
+  const int vec = dt == pda::kBF16 ? 8 : 4;
+  TORCH_CHECK(f2 % 2 == 0 && (f2 / 2) % vec == 0, "swiglu: last dim must be 2*f with f % ", vec, " == 0");
+  auto sizes = x.sizes().vec();
+  sizes.back() = f2 / 2;
+  at::Tensor y = at::empty(sizes, x.options());
+  pda::swiglu_forward(dt, x.data_ptr(), y.data_ptr(), x.numel() / f2, (int)(f2 / 2), current_stream());
+  check_launch("swiglu_forward");
+  return y;
+}
+
+at::Tensor swiglu_backward(const at::Tensor& dy, const at::Tensor& x) {
+  check_gpu(dy, "dy");
+  check_gpu(x, "x");
+  const c10::hip::HIPGuard guard(x.device());
+  const int64_t f2 = x.size(-1);
+  const auto dt = dtype_of(x);
+  const int vec = dt == pda::kBF16 ? 8 : 4;
+  TORCH_CHECK(f2 % 2 == 0 && (f2 / 2) % vec == 0, "swiglu: bad last dim");
+  TORCH_CHECK(dy.scalar_type() == x.scalar_type() && dy.numel() * 2 == x.numel(), "swiglu: dy mismatch");
+  at::Tensor dx = at::empty_like(x);
+  pda::swiglu_backward(dt, dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel() / f2, (int)(f2 / 2),
+                       current_stream());
+  check_launch("swiglu_backward");
+  return dx;
+}
+
+// ---------------------------------------------------------- cross entropy --
+// logits: [rows, ld] view (stride(0) = ld >= vocab, stride(1) = 1); overwritten with the gradient.
+at::Tensor cross_entropy_fwd_bwd(at::Tensor logits, const at::Tensor& targets, int64_t vocab,
+                                 const at::Tensor& grad_scale, int64_t ignore_index) {
+  TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && logits.stride(1) == 1, "ce: bad logits layout");
+  TORCH_CHECK(targets.is_cuda() && targets.scalar_type() == at::kLong && targets.is_contiguous(),
+              "ce: targets must be contiguous int64 on the GPU");
+  TORCH_CHECK(grad_scale.is_cuda() && grad_scale.scalar_type() == at::kFloat && grad_scale.numel() == 1,
+              "ce: grad_scale must be a 1-element float32 GPU tensor");
+  const int64_t rows = logits.size(0);
+  const int64_t ld = logits.stride(0);
+  TORCH_CHECK(targets.numel() == rows, "ce: one target per row");
+  TORCH_CHECK(vocab > 0 && vocab <= ld && vocab <= logits.size(1) + (ld - logits.size(1)),
+              "ce: vocab exceeds the row");
+  // The kernel rewrites the whole padded row [0, ld); the storage must own it.
+  const int64_t elt = logits.element_size();
+  const int64_t end_byte = (logits.storage_offset() + (rows - 1) * ld + ld) * elt;
+  TORCH_CHECK(rows == 0 || end_byte <= (int64_t)logits.storage().nbytes(),
+              "ce: padded rows run past the end of the logits storage");
+  const c10::hip::HIPGuard guard(logits.device());
+  at::Tensor row_loss = at::empty({rows}, logits.options().dtype(at::kFloat));
+  pda::cross_entropy_fwd_bwd(dtype_of(logits), logits.data_ptr(), targets.data_ptr<int64_t>(),
+                             row_loss.data_ptr<float>(), grad_scale.data_ptr<float>(), rows, (int)vocab,
+                             ld, ignore_index, current_stream());
+  check_launch("cross_entropy_fwd_bwd");
+  return row_loss;
+}
+
+// ------------------------------------------------------------------ AdamW --
+void adamw_step(const std::vector<at::Tensor>& params, const std::vector<std::optional<at::Tensor>>& lowp,
+                const std::vector<at::Tensor>& grads, const std::vector<at::Tensor>& exp_avg,
+                const std::vector<at::Tensor>& exp_avg_sq, double lr, double beta1, double beta2,
+                double eps, double weight_decay, int64_t step, double grad_scale, bool zero_grad) {
+  const size_t n = params.size();
+  TORCH_CHECK(grads.size() == n && exp_avg.size() == n && exp_avg_sq.size() == n && lowp.size() == n,
+              "adamw: list lengths differ");
+  if (n == 0) return;
+  TORCH_CHECK(step >= 1, "adamw: step counts from 1");
+  const c10::hip::HIPGuard guard(params[0].device());
+  std::vector<pda::AdamWTensor> ts;
+  ts.reserve(n);
+  const pda::DType gdt = dtype_of(grads[0]);
+  for (size_t i = 0; i < n; ++i) {
+    check_gpu(params[i], "param");
+    check_gpu(grads[i], "grad");
+    check_gpu(exp_avg[i], "exp_avg");
+    check_gpu(exp_avg_sq[i], "exp_avg_sq");
+    TORCH_CHECK(params[i].scalar_type() == at::kFloat && exp_avg[i].scalar_type() == at::kFloat &&
+                    exp_avg_sq[i].scalar_type() == at::kFloat,
+                "adamw: param / state must be float32");
+    TORCH_CHECK(dtype_of(grads[i]) == gdt, "adamw: mixed gradient dtypes in one call");
+    const int64_t numel = params[i].numel();
+    TORCH_CHECK(grads[i].numel() == numel && exp_avg[i].numel() == numel && exp_avg_sq[i].numel() == numel,
+                "adamw: size mismatch at tensor ", i);
+    pda::AdamWTensor t;
+    t.param = params[i].data_ptr<float>();
+    t.lowp = nullptr;
+    if (lowp[i].has_value() && lowp[i]->defined()) {
+      check_gpu(*lowp[i], "lowp");
+      TORCH_CHECK(lowp[i]->scalar_type() == at::kBFloat16 && lowp[i]->numel() == numel, "adamw: bad bf16 mirror");
+      t.lowp = lowp[i]->data_ptr();
+    }
+    t.grad = grads[i].data_ptr();
+    t.exp_avg = exp_avg[i].data_ptr<float>();
+    t.exp_avg_sq = exp_avg_sq[i].data_ptr<float>();
+    t.numel = numel;
+    ts.push_back(t);
+  }
+  pda::AdamWHyper hp;
+  hp.lr = (float)lr;
+  hp.beta1 = (float)beta1;
+  hp.beta2 = (float)beta2;
+  hp.eps = (float)eps;
+  hp.weight_decay = (float)weight_decay;
+  hp.bias_correction1 = (float)(1.0 - std::pow(beta1, (double)step));
+  hp.bias_correction2 = (float)(1.0 - std::pow(beta2, (double)step));
+  hp.grad_scale = (float)grad_scale;
+  pda::adamw_step(ts.data(), (int)n, gdt, hp, zero_grad, current_stream());
+  check_launch("adamw_step");
+}
+
+void accumulate_bf16_into_f32(const at::Tensor& src, at::Tensor dst, double scale) {
+  check_gpu(src, "src");
+  check_gpu(dst, "dst");
+  TORCH_CHECK(src.scalar_type() == at::kBFloat16 && dst.scalar_type() == at::kFloat &&
+                  src.numel() == dst.numel(),
+              "accumulate: expected bf16 src and float32 dst of equal size");
+  const c10::hip::HIPGuard guard(src.device());
+  pda::accumulate_bf16_into_f32(src.data_ptr(), dst.data_ptr<float>(), src.numel(), (float)scale,
+                                current_stream());
+  check_launch("accumulate_bf16_into_f32");
+}
+
+// -------------------------------------------------------------- attention --
+std::vector<at::Tensor> attention_forward(const at::Tensor& qkv, int64_t num_heads, double softmax_scale) {
+  check_gpu(qkv, "qkv");
+  TORCH_CHECK(qkv.scalar_type() == at::kBFloat16, "attention: bf16 only");
+  TORCH_CHECK(qkv.dim() == 3, "attention: qkv must be [B, T, 3*H*D]");
+  const int64_t B = qkv.size(0), T = qkv.size(1), three_hd = qkv.size(2);
+  TORCH_CHECK(three_hd % (3 * num_heads) == 0, "attention: bad qkv width");
+  const int64_t D = three_hd / (3 * num_heads);
+  TORCH_CHECK(D == 64 || D == 128, "attention: head_dim must be 64 or 128, got ", D);
+  TORCH_CHECK(T >= 1 && B >= 1, "attention: empty input");
+  const c10::hip::HIPGuard guard(qkv.device());
+  at::Tensor out = at::empty({B, T, num_heads * D}, qkv.options());
+  at::Tensor lse = at::empty({B, num_heads, T}, qkv.options().dtype(at::kFloat));
+  pda::attention_forward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)T,
+                         (int)num_heads, (int)D, (float)softmax_scale, current_stream());
+  check_launch("attention_forward");
+  return {out, lse};
+}
+
+at::Tensor attention_backward(const at::Tensor& qkv, const at::Tensor& out, const at::Tensor& dout,
+                              const at::Tensor& lse, int64_t num_heads, double softmax_scale) {
+  check_gpu(qkv, "qkv");
+  check_gpu(out, "out");
+  check_gpu(dout, "dout");
+  check_gpu(lse, "lse");
+  TORCH_CHECK(qkv.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16 &&
+                  dout.scalar_type() == at::kBFloat16 && lse.scalar_type() == at::kFloat,
+              "attention backward: dtype mismatch");
+  const int64_t B = qkv.size(0), T = qkv.size(1);
+  const int64_t D = qkv.size(2) / (3 * num_heads);
+  TORCH_CHECK(D == 64 || D == 128, "attention: head_dim must be 64 or 128");
+  TORCH_CHECK(out.numel() == B * T * num_heads * D && dout.numel() == out.numel() &&
+                  lse.numel() == B * num_heads * T,
+              "attention backward: shape mismatch");
+  const c10::hip::HIPGuard guard(qkv.device());
+  at::Tensor dqkv = at::empty_like(qkv);
+  at::Tensor delta = at::empty_like(lse);
+  TORCH_CHECK(false, "attention_backward: kernel not built yet");
+  check_launch("attention_backward");
+  return dqkv;
+}
+
+}  // namespace
+
+void bind_ops(py::module_& m) {
+  m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
+        py::arg("bias"), py::arg("eps"), py::arg("rms"));
+  m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"),
+        py::arg("mean"), py::arg("rstd"), py::arg("dresidual"), py::arg("rms"));
+  m.def("gelu_forward", &gelu_forward);
+  m.def("gelu_backward", &gelu_backward);
+  m.def("swiglu_forward", &swiglu_forward);
+  m.def("swiglu_backward", &swiglu_backward);
+  m.def("cross_entropy_fwd_bwd", &cross_entropy_fwd_bwd, py::arg("logits"), py::arg("targets"),
+        py::arg("vocab"), py::arg("grad_scale"), py::arg("ignore_index"));
+  m.def("adamw_step", &adamw_step, py::arg("params"), py::arg("lowp"), py::arg("grads"),
+        py::arg("exp_avg"), py::arg("exp_avg_sq"), py::arg("lr"), py::arg("beta1"), py::arg("beta2"),
+        py::arg("eps"), py::arg("weight_decay"), py::arg("step"), py::arg("grad_scale"),
+        py::arg("zero_grad"));
+  m.def("accumulate_bf16_into_f32", &accumulate_bf16_into_f32);
+  m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("num_heads"),
+        py::arg("softmax_scale"));
+  m.def("attention_backward", &attention_backward, py::arg("qkv"), py::arg("out"), py::arg("dout"),
+        py::arg("lse"), py::arg("num_heads"), py::arg("softmax_scale"));
+}

@@ -1,0 +1,140 @@
+// Shared pieces of the causal attention kernels (forward, dQ, dK/dV) for gfx950.
+//
+// Data layout. The kernels read the packed QKV activation the c_attn GEMM
+// produces, [B, T, 3, H, D] bf16, directly (token stride 3*H*D), and write
+// [B, T, H, D] outputs, so no split / transpose / reshape copy exists on
+// either side (the reference materialises three of them plus the T x T score
+// matrix: assignments/assignment1/model/my_gpt2.py:43-48,63-76).
+//
+// MFMA tiling. Everything is built from v_mfma_f32_32x32x16_bf16 with the
+// "reduction index on the registers, free index on the lane" orientation: a
+// 32x32 fp32 result tile keeps its column on the lane (lane & 31) and its 32
+// rows spread over 16 registers x 2 lane halves. A following product that
+// sums over the rows of such a tile takes it straight from the accumulator
+// registers as its B operand (converted to bf16), provided the other operand
+// is fed in the same permuted k order:
+//     element j of lane-half h  <->  row 16*s + 8*(j>>2) + 4*h + (j&3)
+// for k-step s. The transposed LDS read ds_read_b64_tr_b16 delivers exactly
+// that order from a row-major tile, so P (forward) and dS (backward) never
+// travel through LDS.
+//
+// LDS tiles are row-major [rows][D] bf16 with the 16-byte chunk index XOR
+// swizzled (tile_off) so that both access shapes are bank-conflict free:
+//   * "row reads"  (ds_read_b128, one row per lane, same chunk in all lanes)
+//   * "transposed reads" (ds_read_b64_tr_b16, 4 rows x 64 bytes per 32 lanes)
+#pragma once
+
+#include "common.h"
+
+namespace pda {
+namespace attn {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// Byte offset of 16-byte chunk `chunk` of row `row` in an LDS tile. The XOR
+// term serves both access shapes at once:
+//   D = 64 (128-byte rows, two rows per 256-byte bank row): a row read touches
+//   16 rows distinct mod 16 at one chunk -> (row&1, bits 1..3 of row) must map
+//   to 16 different 16-byte slots; a transposed read touches rows 4a..4a+3 x
+//   4 chunks of one 64-byte segment -> bit 1 of the row must flip the segment.
+//   D = 128 (256-byte rows): rows mod 16 must permute all 16 slots, and
+//   row & 3 must select the segment.
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  if constexpr (D == 64) {
+    const int x = (((row >> 1) & 1) << 2) | ((row >> 2) & 1) | (((row >> 3) & 1) << 1);
+    return row * 128 + ((chunk ^ x) << 4);
+  } else {
+    const int x = ((row & 3) << 2) | ((row >> 2) & 3);
+    return row * 256 + ((chunk ^ x) << 4);
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_read_b128(const char* lds, int byte_off) {
+  return *reinterpret_cast<const bf16x8*>(lds + byte_off);
+}
+
+// One ds_read_b64_tr_b16: within each group of 16 lanes, lane i receives
+// column i of a 4-row x 16-column block; lane 4q+p supplies the address of
+// row q, columns 4p..4p+3. Must execute with all 64 lanes active.
+__device__ __forceinline__ s16x4 lds_read_tr(const char* lds, int byte_off) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4*)(__attribute__((address_space(3))) char*)(lds + byte_off));
+}
+
+// A-operand fragment (32 rows of the transposed tile x 16 k) for k-step
+// `kstep` and 32-column block `cblock` of a transposed-read tile holding
+// [k rows][D columns]: returns, for lane (r = lane&31, h = lane>>5), the 8
+// values tile[16*kstep + 8*(j>>2) + 4*h + (j&3)][32*cblock + r], j = 0..7.
+template <int D>
+__device__ __forceinline__ bf16x8 tr_fragment(const char* tile, int kstep, int cblock, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int q = i >> 2, p = i & 3;
+  const int h = g >> 1;
+  const int col = cblock * 32 + 16 * (g & 1) + 4 * p;  // first of 4 columns this lane addresses
+  const int row0 = 16 * kstep + 4 * h + q;
+  const int chunk = col >> 3, within = (col & 7) * 2;
+  s16x4 lo = lds_read_tr(tile, tile_off<D>(row0, chunk) + within);
+  s16x4 hi = lds_read_tr(tile, tile_off<D>(row0 + 8, chunk) + within);
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Eight consecutive accumulator registers -> one bf16 B-operand fragment.
+__device__ __forceinline__ bf16x8 pack_acc8(float a0, float a1, float a2, float a3, float a4, float a5,
+                                            float a6, float a7) {
+  u32x4 w = {pack_bf16x2(a0, a1), pack_bf16x2(a2, a3), pack_bf16x2(a4, a5), pack_bf16x2(a6, a7)};
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Row index, inside a 32-row accumulator tile, of register `reg` for lane-half `h`.
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float lane_pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float lane_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// Cooperative copy of a [kRows][D] bf16 tile from global memory (row stride
+// `row_stride` elements, rows clamped to `last_row`) into registers and from
+// registers into an LDS tile. Split in two so the global latency hides under
+// compute (issue early, write late).
+template <int D, int kRows, int kThreads>
+struct TileStager {
+  static constexpr int kChunksPerRow = D / 8;
+  static constexpr int kChunks = kRows * kChunksPerRow;
+  static constexpr int kPerThread = (kChunks + kThreads - 1) / kThreads;
+  u32x4 regs[kPerThread];
+
+  __device__ __forceinline__ void load(const bf16_raw* base, int64_t row_stride, int row0, int last_row,
+                                       int tid) {
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+      const int c = tid + i * kThreads;
+      if (kChunks % kThreads == 0 || c < kChunks) {
+        int row = row0 + c / kChunksPerRow;
+        row = row < last_row ? row : last_row;
+        regs[i] = *reinterpret_cast<const u32x4*>(base + int64_t(row) * row_stride + (c % kChunksPerRow) * 8);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < kPerThread; ++i) {
+      const int c = tid + i * kThreads;
+      if (kChunks % kThreads == 0 || c < kChunks) {
+        const int row = c / kChunksPerRow, chunk = c % kChunksPerRow;
+        *reinterpret_cast<u32x4*>(tile + tile_off<D>(row, chunk)) = regs[i];
+      }
+    }
+  }
+};
+
+}  // namespace attn
+}  // namespace pda

@@ -1,0 +1,354 @@
+// LayerNorm / RMSNorm forward and backward for gfx950.
+//
+// Mapping: one row per 64-lane wave, 4 waves per workgroup. A lane owns the
+// 16-byte vectors lane, lane+64, lane+128, ... of its row and keeps them in
+// registers between the statistics pass and the normalise pass, so every row
+// is read from HBM exactly once and written once. Row statistics are wave
+// reductions (no LDS, no barrier). The optional residual add is fused into the
+// forward (emits the new residual stream too) and the incoming residual
+// gradient into the backward, which removes the stand-alone elementwise adds
+// of the pre-norm transformer block
+// (reference block structure: assignments/assignment1/model/my_gpt2.py:121-134).
+//
+// Backward additionally needs column sums over all rows (dweight, dbias). Each
+// wave accumulates its columns in registers while it walks its rows, the four
+// waves of a block are combined through LDS, and every block writes one fp32
+// partial row; norm_reduce_partials folds the <= 512 partial rows.
+#include "common.h"
+#include "pda_kernels.h"
+
+namespace pda {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = kThreads / kWave;
+constexpr int kMaxPartialRows = 512;
+
+template <typename T, int kMaxIt, bool kRms, bool kHasRes>
+__global__ __launch_bounds__(kThreads) void norm_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ w,
+    const T* __restrict__ b, T* __restrict__ y, T* __restrict__ sum_out, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, int64_t rows, int d, float eps) {
+  constexpr int kVec = VecIO<T>::kVec;
+  const int lane = threadIdx.x & 63;
+  const int nvec = d / kVec;
+  const float inv_d = 1.f / (float)d;
+  const int64_t wave_global = int64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t wave_stride = int64_t(gridDim.x) * kWavesPerBlock;
+
+  for (int64_t row = wave_global; row < rows; row += wave_stride) {
+    const T* xr = x + row * d;
+    float v[kMaxIt][kVec];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int vi = lane + it * 64;
+      if (vi < nvec) {
+        VecIO<T>::load(xr + vi * kVec, v[it]);
+        if (kHasRes) {
+          float r[kVec];
+          VecIO<T>::load(res + row * d + vi * kVec, r);
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) v[it][k] += r[k];
+          VecIO<T>::store(sum_out + row * d + vi * kVec, v[it]);
+          if constexpr (sizeof(T) == 2) {
+            // Normalise what later kernels will read back: the bf16-rounded sum.
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[it][k] = bf16_to_f32(f32_to_bf16(v[it][k]));
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) s += kRms ? v[it][k] * v[it][k] : v[it][k];
+      }
+    }
+    float mean = 0.f, rstd;
+    if (kRms) {
+      rstd = rsqrtf(wave_sum(s) * inv_d + eps);
+    } else {
+      mean = wave_sum(s) * inv_d;
+      float q = 0.f;
+#pragma unroll
+      for (int it = 0; it < kMaxIt; ++it) {
+        if (lane + it * 64 < nvec) {
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) {
+            const float c = v[it][k] - mean;
+            q += c * c;
+          }
+        }
+      }
+      rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    }
+    if (lane == 0) {
+      if (!kRms) mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int vi = lane + it * 64;
+      if (vi < nvec) {
+        float wv[kVec], o[kVec];
+        VecIO<T>::load(w + vi * kVec, wv);
+        if (kRms) {
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) o[k] = v[it][k] * rstd * wv[k];
+        } else {
+          float bv[kVec];
+          VecIO<T>::load(b + vi * kVec, bv);
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) o[k] = (v[it][k] - mean) * rstd * wv[k] + bv[k];
+        }
+        VecIO<T>::store(y + row * d + vi * kVec, o);
+      }
+    }
+  }
+}
+
+template <typename T, int kMaxIt, bool kRms, bool kHasRes>
+__global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dw_partial,
+    float* __restrict__ db_partial, int64_t rows, int d) {
+  constexpr int kVec = VecIO<T>::kVec;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int nvec = d / kVec;
+  const float inv_d = 1.f / (float)d;
+  const int64_t wave_global = int64_t(blockIdx.x) * kWavesPerBlock + wid;
+  const int64_t wave_stride = int64_t(gridDim.x) * kWavesPerBlock;
+
+  float dw_acc[kMaxIt][kVec];
+  float db_acc[kRms ? 1 : kMaxIt][kVec];
+  float wv[kMaxIt][kVec];
+#pragma unroll
+  for (int it = 0; it < kMaxIt; ++it) {
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) {
+      dw_acc[it][k] = 0.f;
+      if constexpr (!kRms) db_acc[it][k] = 0.f;
+      wv[it][k] = 0.f;
+    }
+    const int vi = lane + it * 64;
+    if (vi < nvec) VecIO<T>::load(w + vi * kVec, wv[it]);
+  }
+
+  for (int64_t row = wave_global; row < rows; row += wave_stride) {
+    const float mean = kRms ? 0.f : mean_in[row];
+    const float rstd = rstd_in[row];
+    typename VecIO<T>::Raw dy_raw[kMaxIt], x_raw[kMaxIt];  // kept packed between the passes
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int vi = lane + it * 64;
+      if (vi < nvec) {
+        float dyv[kVec], xv[kVec];
+        dy_raw[it] = VecIO<T>::load_raw(dy + row * d + vi * kVec);
+        x_raw[it] = VecIO<T>::load_raw(x + row * d + vi * kVec);
+        VecIO<T>::unpack(dy_raw[it], dyv);
+        VecIO<T>::unpack(x_raw[it], xv);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+          const float xhat = (xv[k] - mean) * rstd;
+          const float gg = dyv[k] * wv[it][k];
+          c1 += gg * xhat;
+          if (!kRms) c2 += gg;
+          dw_acc[it][k] += dyv[k] * xhat;
+          if constexpr (!kRms) db_acc[it][k] += dyv[k];
+        }
+      }
+    }
+    c1 = wave_sum(c1) * inv_d;
+    if (!kRms) c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int vi = lane + it * 64;
+      if (vi < nvec) {
+        float dyv[kVec], xv[kVec], o[kVec];
+        VecIO<T>::unpack(dy_raw[it], dyv);
+        VecIO<T>::unpack(x_raw[it], xv);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+          const float xhat = (xv[k] - mean) * rstd;
+          o[k] = (dyv[k] * wv[it][k] - c2 - xhat * c1) * rstd;
+        }
+        if (kHasRes) {
+          float r[kVec];
+          VecIO<T>::load(dres + row * d + vi * kVec, r);
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) o[k] += r[k];
+        }
+        VecIO<T>::store(dx + row * d + vi * kVec, o);
+      }
+    }
+  }
+
+  // Combine the 4 waves' column sums through LDS, then one partial row per block.
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][d]
+  for (int pass = 0; pass < (kRms ? 1 : 2); ++pass) {
+    __syncthreads();
+    if (wid > 0) {
+#pragma unroll
+      for (int it = 0; it < kMaxIt; ++it) {
+        const int vi = lane + it * 64;
+        if (vi < nvec) {
+#pragma unroll
+          for (int k = 0; k < kVec; ++k)
+            smem[(wid - 1) * d + vi * kVec + k] = pass == 0 ? dw_acc[it][k] : db_acc[kRms ? 0 : it][k];
+        }
+      }
+    }
+    __syncthreads();
+    if (wid == 0) {
+      float* outp = (pass == 0 ? dw_partial : db_partial) + int64_t(blockIdx.x) * d;
+#pragma unroll
+      for (int it = 0; it < kMaxIt; ++it) {
+        const int vi = lane + it * 64;
+        if (vi < nvec) {
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) {
+            const int c = vi * kVec + k;
+            float a = pass == 0 ? dw_acc[it][k] : db_acc[kRms ? 0 : it][k];
+            a += smem[c] + smem[d + c] + smem[2 * d + c];
+            outp[c] = a;
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[c] (+)= sum_r partial[r][c]. Block = 64 columns x 4 row groups.
+template <typename OutT>
+__global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                                   int partial_rows, int d,
+                                                                   OutT* __restrict__ out,
+                                                                   bool accumulate) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < d) {
+    for (int r = rg; r < partial_rows; r += 4) acc += partial[int64_t(r) * d + c];
+  }
+  sm[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && c < d) {
+    float t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (accumulate) t += VecIO<OutT>::load1(out + c);
+    VecIO<OutT>::store1(out + c, t);
+  }
+}
+
+inline unsigned fwd_grid(int64_t rows) {
+  int64_t blocks = ceil_div(rows, kWavesPerBlock);
+  if (blocks > 4096) blocks = 4096;
+  return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+template <typename T, int kMaxIt>
+void launch_fwd(bool rms, const void* x, const void* res, const void* w, const void* b, void* y,
+                void* sum_out, float* mean, float* rstd, int64_t rows, int d, float eps,
+                hipStream_t stream) {
+  dim3 grid(fwd_grid(rows)), block(kThreads);
+#define PDA_FWD(RMS, RES)                                                                        \
+  hipLaunchKernelGGL((norm_fwd_kernel<T, kMaxIt, RMS, RES>), grid, block, 0, stream, (const T*)x, \
+                     (const T*)res, (const T*)w, (const T*)b, (T*)y, (T*)sum_out, mean, rstd,     \
+                     rows, d, eps)
+  if (rms) {
+    if (res) PDA_FWD(true, true); else PDA_FWD(true, false);
+  } else {
+    if (res) PDA_FWD(false, true); else PDA_FWD(false, false);
+  }
+#undef PDA_FWD
+}
+
+template <typename T, int kMaxIt>
+void launch_bwd(bool rms, const void* dy, const void* x, const void* w, const float* mean,
+                const float* rstd, const void* dres, void* dx, float* dwp, float* dbp, int64_t rows,
+                int d, hipStream_t stream) {
+  dim3 grid(norm_backward_partial_rows(rows)), block(kThreads);
+  const size_t lds = size_t(3) * d * sizeof(float);
+#define PDA_BWD(RMS, RES)                                                                          \
+  do {                                                                                             \
+    if (lds > 65536)                                                                               \
+      (void)hipFuncSetAttribute((const void*)norm_bwd_kernel<T, kMaxIt, RMS, RES>,                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+    hipLaunchKernelGGL((norm_bwd_kernel<T, kMaxIt, RMS, RES>), grid, block, lds, stream,           \
+                       (const T*)dy, (const T*)x, (const T*)w, mean, rstd, (const T*)dres, (T*)dx, \
+                       dwp, dbp, rows, d);                                                         \
+  } while (0)
+  if (rms) {
+    if (dres) PDA_BWD(true, true); else PDA_BWD(true, false);
+  } else {
+    if (dres) PDA_BWD(false, true); else PDA_BWD(false, false);
+  }
+#undef PDA_BWD
+}
+
+template <typename T>
+int iters_for(int d) {
+  const int nvec = d / VecIO<T>::kVec;
+  return (nvec + 63) / 64;
+}
+
+}  // namespace
+
+int norm_backward_partial_rows(int64_t rows) {
+  int64_t blocks = ceil_div(rows, kWavesPerBlock);
+  if (blocks > kMaxPartialRows) blocks = kMaxPartialRows;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+void norm_forward(DType dtype, bool rms, const void* x, const void* residual, const void* weight,
+                  const void* bias, void* y, void* sum_out, float* mean, float* rstd, int64_t rows,
+                  int d, float eps, hipStream_t stream) {
+  if (rows <= 0) return;
+#define PDA_DISPATCH(T)                                                                              \
+  do {                                                                                               \
+    const int it = iters_for<T>(d);                                                                  \
+    if (it <= 2) launch_fwd<T, 2>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
+    else if (it <= 3) launch_fwd<T, 3>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
+    else if (it <= 4) launch_fwd<T, 4>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
+    else if (it <= 8) launch_fwd<T, 8>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
+    else launch_fwd<T, 16>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
+  } while (0)
+  if (dtype == kBF16) PDA_DISPATCH(bf16_raw); else PDA_DISPATCH(float);
+#undef PDA_DISPATCH
+}
+
+void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const void* weight,
+                   const float* mean, const float* rstd, const void* dresidual, void* dx,
+                   float* dw_partial, float* db_partial, int64_t rows, int d, hipStream_t stream) {
+  if (rows <= 0) return;
+#define PDA_DISPATCH(T)                                                                              \
+  do {                                                                                               \
+    const int it = iters_for<T>(d);                                                                  \
+    if (it <= 2) launch_bwd<T, 2>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
+    else if (it <= 3) launch_bwd<T, 3>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
+    else if (it <= 4) launch_bwd<T, 4>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
+    else if (it <= 8) launch_bwd<T, 8>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
+    else launch_bwd<T, 16>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
+  } while (0)
+  if (dtype == kBF16) PDA_DISPATCH(bf16_raw); else PDA_DISPATCH(float);
+#undef PDA_DISPATCH
+}
+
+void norm_reduce_partials(const float* dw_partial, const float* db_partial, int partial_rows, int d,
+                          DType out_dtype, void* dweight, void* dbias, bool accumulate,
+                          hipStream_t stream) {
+  dim3 grid((d + 63) / 64), block(kThreads);
+  for (int which = 0; which < 2; ++which) {
+    const float* src = which == 0 ? dw_partial : db_partial;
+    void* dst = which == 0 ? dweight : dbias;
+    if (!src || !dst) continue;
+    if (out_dtype == kBF16)
+      hipLaunchKernelGGL(reduce_partials_kernel<bf16_raw>, grid, block, 0, stream, src, partial_rows,
+                         d, (bf16_raw*)dst, accumulate);
+    else
+      hipLaunchKernelGGL(reduce_partials_kernel<float>, grid, block, 0, stream, src, partial_rows, d,
+                         (float*)dst, accumulate);
+  }
+}
+
+}  // namespace pda

@@ -1,0 +1,101 @@
+// Host-side launch API of the hand-written gfx950 kernels.
+//
+// The kernels know nothing about PyTorch: every entry point takes raw device
+// pointers, sizes and a HIP stream, so each can be driven from the Python
+// binding (bindings.cpp) or from a stand-alone C++ benchmark under rocprofv3.
+// No entry point allocates, frees or synchronises, so all of them are safe
+// inside a hipGraph capture.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace pda {
+
+enum DType : int { kF32 = 0, kBF16 = 1 };
+
+// ------------------------------------------------------------------ AdamW --
+struct AdamWHyper {
+  float lr;
+  float beta1;
+  float beta2;
+  float eps;
+  float weight_decay;
+  float bias_correction1;  // 1 - beta1^t
+  float bias_correction2;  // 1 - beta2^t
+  float grad_scale;        // gradients are multiplied by this before use
+};
+
+// One tensor of a multi-tensor AdamW step. `param` is the fp32 value that is
+// updated in place (the parameter itself for fp32 models, the master copy for
+// bf16 models); `lowp` (optional) receives a bf16 copy of the updated value.
+struct AdamWTensor {
+  float* param;
+  void* lowp;        // bf16 mirror or nullptr
+  void* grad;        // fp32 or bf16, see grad_dtype
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+};
+
+// Decoupled-weight-decay Adam over `n` tensors in as few launches as possible
+// (large tensors get one grid-stride launch each, small ones are packed).
+// If zero_grad is set the gradient is overwritten with zeros once consumed.
+void adamw_step(const AdamWTensor* tensors, int n, DType grad_dtype, const AdamWHyper& hp,
+                bool zero_grad, hipStream_t stream);
+
+// ----------------------------------------------------- LayerNorm / RMSNorm --
+// y = LN(x [+ residual]) * w + b over rows of length d. If `residual` is given
+// the sum x + residual is also written to `sum_out` (the new residual stream).
+// mean / rstd are fp32 [rows]. RMSNorm passes bias = nullptr, mean = nullptr
+// and rms = true. Requires d % (16 / sizeof(T)) == 0 and 16-byte aligned rows.
+void norm_forward(DType dtype, bool rms, const void* x, const void* residual, const void* weight,
+                  const void* bias, void* y, void* sum_out, float* mean, float* rstd,
+                  int64_t rows, int d, float eps, hipStream_t stream);
+
+// dx = dLN/dx (+ dresidual if given). Column reductions for dweight / dbias
+// are produced as fp32 partial sums [norm_backward_partial_rows(rows), d] and
+// folded by norm_reduce_partials into fp32 dweight / dbias (accumulate=true
+// adds to the existing contents instead of overwriting).
+int norm_backward_partial_rows(int64_t rows);
+void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const void* weight,
+                   const float* mean, const float* rstd, const void* dresidual, void* dx,
+                   float* dw_partial, float* db_partial, int64_t rows, int d, hipStream_t stream);
+void norm_reduce_partials(const float* dw_partial, const float* db_partial, int partial_rows, int d,
+                          DType out_dtype, void* dweight, void* dbias, bool accumulate,
+                          hipStream_t stream);
+
+// -------------------------------------------------------------- Activations --
+// tanh-approximated GELU ("gelu_new"): y = 0.5 u (1 + tanh(sqrt(2/pi)(u + 0.044715 u^3))).
+void gelu_forward(DType dtype, const void* u, void* y, int64_t n, hipStream_t stream);
+void gelu_backward(DType dtype, const void* dy, const void* u, void* du, int64_t n, hipStream_t stream);
+// SwiGLU over x = [gate | up] rows of length 2*f: y = silu(gate) * up.
+void swiglu_forward(DType dtype, const void* x, void* y, int64_t rows, int f, hipStream_t stream);
+void swiglu_backward(DType dtype, const void* dy, const void* x, void* dx, int64_t rows, int f,
+                     hipStream_t stream);
+
+// --------------------------------------------------- Softmax cross-entropy --
+// One pass over logits [rows, ld] (only the first `vocab` columns are real):
+// writes per-row loss = logsumexp - logit[target] (0 where target == ignore_index)
+// and replaces the logits IN PLACE with (softmax - onehot) * (*grad_scale)
+// (0 for ignored rows and for the padding columns vocab..ld-1).
+void cross_entropy_fwd_bwd(DType dtype, void* logits, const int64_t* targets, float* row_loss,
+                           const float* grad_scale, int64_t rows, int vocab, int64_t ld,
+                           int64_t ignore_index, hipStream_t stream);
+
+// ----------------------------------------------------------------- Attention --
+// Causal self-attention over a packed QKV activation [B, T, 3, H, D] (bf16),
+// D in {64, 128}. out is [B, T, H, D] bf16, lse is [B, H, T] fp32 (natural log).
+void attention_forward(const void* qkv, void* out, float* lse, int B, int T, int H, int D,
+                       float softmax_scale, hipStream_t stream);
+// dqkv has the layout of qkv. delta is an fp32 [B, H, T] workspace.
+void attention_backward(const void* qkv, const void* out, const void* dout, const float* lse,
+                        float* delta, void* dqkv, int B, int T, int H, int D, float softmax_scale,
+                        hipStream_t stream);
+
+// ----------------------------------------------------------------- Utilities --
+// dst(fp32) += src(bf16) * scale, and plain casts, for main-grad accumulation.
+void accumulate_bf16_into_f32(const void* src_bf16, float* dst, int64_t n, float scale, hipStream_t stream);
+void cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, hipStream_t stream);
+
+}  // namespace pda

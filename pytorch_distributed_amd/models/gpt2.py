@@ -1,0 +1,227 @@
+"""GPT-2 with the reference's module tree and ``state_dict`` schema, built from the
+fused ops of :mod:`pytorch_distributed_amd.ops`.
+
+Public surface kept from the reference (assignments/assignment1/model/my_gpt2.py):
+``MyGPT2Attention`` / ``MyGPT2MLP`` / ``MyGPT2Block`` / ``MyGPT2Model`` /
+``MyGPT2LMHeadModel(config, enable_activation_checkpoint=True)``, ``forward(input_ids)
+-> logits``, ``init_weights``, ``device``, ``save``, ``from_pretrained``,
+``from_hf_pretrained``, ``from_hf_config`` and the parameter names
+``transformer.{wte,wpe}.weight``, ``transformer.h.N.{ln_1,attn.c_attn,attn.c_proj,
+ln_2,mlp.c_fc,mlp.c_proj}.{weight,bias}``, ``transformer.ln_f.*``, ``lm_head.weight``
+(tied to ``wte``), so checkpoints move between the two implementations unchanged.
+
+What is different underneath:
+
+* attention is one fused causal kernel over the packed QKV activation; there is no
+  ``causal_mask`` buffer (the reference registers a ``[1,1,n_ctx,n_ctx]`` bool buffer per
+  layer, my_gpt2.py:28-36, which DDP then re-broadcasts every forward);
+* the residual stream is carried between blocks as a ``(delta, residual)`` pair so each
+  LayerNorm kernel also performs the preceding residual add;
+* ``forward(input_ids, targets)`` returns the mean cross-entropy through the fused
+  LM-head + softmax-CE op, never materialising fp32 logits;
+* activation memory follows the reference's selective-checkpoint policy structurally:
+  the fused ops keep matmul outputs plus per-row statistics and recompute the cheap
+  element-wise work in backward. ``activation_checkpoint="full"`` additionally
+  recomputes whole blocks.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+from .. import ops
+from .config import GPT2Config, get_config, normalize_gpt2_config
+
+
+class MyGPT2Attention(nn.Module):
+    """Fused-QKV multi-head causal self-attention."""
+
+    def __init__(self, config):
+        super().__init__()
+        config = normalize_gpt2_config(config)
+        self.embed_dim = config.n_embd
+        self.num_heads = config.n_head
+        self.head_dim = self.embed_dim // self.num_heads
+        self.c_attn = nn.Linear(self.embed_dim, 3 * self.embed_dim, bias=True)
+        self.c_proj = nn.Linear(self.embed_dim, self.embed_dim, bias=True)
+        self.attn_pdrop = float(config.attn_pdrop)
+        self.resid_dropout = nn.Dropout(p=config.resid_pdrop)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        qkv = self.c_attn(hidden_states)  # [B, T, 3d], consumed in place by the attention kernel
+        ctx = ops.causal_attention(qkv, self.num_heads, dropout_p=self.attn_pdrop, training=self.training)
+        return self.resid_dropout(self.c_proj(ctx))
+
+
+class MyGPT2MLP(nn.Module):
+    """d -> 4d -> gelu_new -> d."""
+
+    def __init__(self, config):
+        super().__init__()
+        config = normalize_gpt2_config(config)
+        if config.activation_function not in ("gelu_new", "gelu_pytorch_tanh"):
+            raise ValueError(f"unsupported activation {config.activation_function!r} (GPT-2 uses gelu_new)")
+        self.embed_dim = config.n_embd
+        self.c_fc = nn.Linear(self.embed_dim, 4 * self.embed_dim, bias=True)
+        self.c_proj = nn.Linear(4 * self.embed_dim, self.embed_dim, bias=True)
+        self.dropout = nn.Dropout(p=config.resid_pdrop)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        return self.dropout(self.c_proj(ops.gelu_new(self.c_fc(hidden_states))))
+
+
+class MyGPT2Block(nn.Module):
+    """Pre-LayerNorm transformer block.
+
+    ``block(x)`` maps a hidden state to a hidden state like the reference's block.
+    ``block(delta, residual)`` is the fused form used by :class:`MyGPT2Model`: the
+    block's input is ``delta + residual`` (added inside the first LayerNorm kernel) and
+    the result is returned as the pair ``(mlp_out, residual')`` whose sum is the block's
+    output, left un-added for the next block's LayerNorm to fuse.
+    """
+
+    def __init__(self, config):
+        super().__init__()
+        config = normalize_gpt2_config(config)
+        self.embed_dim = config.n_embd
+        self.ln_1 = nn.LayerNorm(self.embed_dim, eps=config.layer_norm_epsilon)
+        self.attn = MyGPT2Attention(config)
+        self.ln_2 = nn.LayerNorm(self.embed_dim, eps=config.layer_norm_epsilon)
+        self.mlp = MyGPT2MLP(config)
+
+    def _run(self, delta, residual) -> Tuple[torch.Tensor, torch.Tensor]:
+        y, h = ops.fused_add_layer_norm(delta, residual, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+        a = self.attn(y)
+        y, h = ops.fused_add_layer_norm(a, h, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
+        return self.mlp(y), h
+
+    def forward(self, hidden_state: torch.Tensor, residual: Optional[torch.Tensor] = None, *,
+                fused: bool = False):
+        out, h = self._run(hidden_state, residual)
+        if fused:
+            return out, h
+        return out + h
+
+
+class MyGPT2Model(nn.Module):
+    """Embeddings, ``n_layer`` blocks, final LayerNorm."""
+
+    def __init__(self, config, enable_activation_checkpoint: bool = True,
+                 activation_checkpoint: str = "selective"):
+        super().__init__()
+        config = normalize_gpt2_config(config)
+        if activation_checkpoint not in ("selective", "full", "none"):
+            raise ValueError("activation_checkpoint must be 'selective', 'full' or 'none'")
+        self.enable_activation_checkpoint = enable_activation_checkpoint
+        self.activation_checkpoint = activation_checkpoint
+        self.wte = nn.Embedding(config.vocab_size, config.n_embd)
+        self.wpe = nn.Embedding(config.n_ctx, config.n_embd)
+        self.drop = nn.Dropout(p=config.embd_pdrop)
+        self.h = nn.ModuleList([MyGPT2Block(config) for _ in range(config.n_layer)])
+        self.ln_f = nn.LayerNorm(config.n_embd, eps=config.layer_norm_epsilon)
+        self.n_ctx = config.n_ctx
+
+    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        _, seq_len = input_ids.shape
+        if seq_len > self.n_ctx:
+            raise ValueError(f"sequence length {seq_len} exceeds n_ctx {self.n_ctx}")
+        positions = torch.arange(seq_len, device=input_ids.device)
+        delta = self.drop(self.wte(input_ids) + self.wpe(positions))
+        residual = None
+        full_recompute = (self.enable_activation_checkpoint and self.training
+                          and self.activation_checkpoint == "full")
+        for block in self.h:
+            if full_recompute:
+                delta, residual = checkpoint(block, delta, residual, fused=True, use_reentrant=False)
+            else:
+                delta, residual = block(delta, residual, fused=True)
+        out, _ = ops.fused_add_layer_norm(delta, residual, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)
+        return out
+
+
+class MyGPT2LMHeadModel(nn.Module):
+    """GPT-2 with the LM head tied to the token embedding."""
+
+    def __init__(self, config, enable_activation_checkpoint: bool = True,
+                 activation_checkpoint: str = "selective"):
+        super().__init__()
+        config = normalize_gpt2_config(config)
+        self.config = config
+        self.transformer = MyGPT2Model(config, enable_activation_checkpoint, activation_checkpoint)
+        self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False)
+        self.lm_head.weight = self.transformer.wte.weight  # one Parameter, two names
+        self.init_weights()
+
+    def forward(self, input_ids: torch.Tensor, targets: Optional[torch.Tensor] = None,
+                ignore_index: int = -100) -> torch.Tensor:
+        """``forward(ids)`` -> logits ``[B, T, V]``; ``forward(ids, targets)`` -> mean cross-entropy."""
+        hidden = self.transformer(input_ids)
+        if targets is None:
+            return self.lm_head(hidden)
+        return ops.lm_head_cross_entropy(hidden, self.lm_head.weight, targets, ignore_index)
+
+    @torch.no_grad()
+    def init_weights(self) -> None:
+        """OpenAI GPT-2 initialisation: N(0, 0.02) for every Linear weight and for ``wte``,
+        N(0, 0.01) for ``wpe``, zero biases, unit LayerNorm (same constants as the reference,
+        my_gpt2.py:216-244)."""
+        for module in self.modules():
+            if isinstance(module, nn.Linear):
+                module.weight.normal_(0.0, 0.02)
+                if module.bias is not None:
+                    module.bias.zero_()
+            elif isinstance(module, nn.LayerNorm):
+                module.weight.fill_(1.0)
+                module.bias.zero_()
+        self.transformer.wte.weight.normal_(0.0, 0.02)
+        self.transformer.wpe.weight.normal_(0.0, 0.01)
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def num_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    def save(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    # ------------------------------------------------------------------ import / export
+    @staticmethod
+    def _convert_conv1d_to_linear_state_dict(state_dict):
+        """HF GPT-2 stores c_attn / c_proj / c_fc as Conv1D with weight ``[in, out]``;
+        nn.Linear wants ``[out, in]``. Transposes exactly those weights."""
+        converted = {}
+        for key, value in state_dict.items():
+            is_conv1d = any(tag in key for tag in ("c_attn", "c_proj", "c_fc"))
+            converted[key] = value.t().contiguous() if (is_conv1d and "weight" in key) else value
+        return converted
+
+    @staticmethod
+    def from_pretrained(state_dict, config=None, enable_activation_checkpoint: bool = True) -> "MyGPT2LMHeadModel":
+        model = MyGPT2LMHeadModel(config if config is not None else get_config("gpt2"),
+                                  enable_activation_checkpoint=enable_activation_checkpoint)
+        state_dict = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        # HF checkpoints carry per-layer mask buffers this model does not have.
+        state_dict = {k: v for k, v in state_dict.items()
+                      if not k.endswith((".attn.bias", ".attn.masked_bias", ".causal_mask"))}
+        model.load_state_dict(state_dict)
+        return model
+
+    @staticmethod
+    def from_hf_pretrained(model_name: str = "gpt2", enable_activation_checkpoint: bool = True) -> "MyGPT2LMHeadModel":
+        """Loads Hugging Face weights (needs ``transformers`` and a populated local cache)."""
+        from transformers import AutoModelForCausalLM
+
+        hf_model = AutoModelForCausalLM.from_pretrained(model_name)
+        sd = MyGPT2LMHeadModel._convert_conv1d_to_linear_state_dict(hf_model.state_dict())
+        return MyGPT2LMHeadModel.from_pretrained(sd, normalize_gpt2_config(hf_model.config),
+                                                 enable_activation_checkpoint)
+
+    @classmethod
+    def from_hf_config(cls, model_name: str = "gpt2", enable_activation_checkpoint: bool = True) -> "MyGPT2LMHeadModel":
+        """Random-init model with the named configuration (built-in table, no download)."""
+        return cls(get_config(model_name), enable_activation_checkpoint=enable_activation_checkpoint)

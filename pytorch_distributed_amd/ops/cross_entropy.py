@@ -1,0 +1,113 @@
+"""LM head + softmax cross-entropy, fused.
+
+``lm_head_cross_entropy(hidden, weight, targets)`` computes
+``cross_entropy(hidden @ weight.T, targets)`` (mean over non-ignored targets)
+— the reference's ``lm_head`` GEMM followed by ``F.cross_entropy``
+(assignments/assignment1/model/my_gpt2.py:211-214,
+assignments/assignment1/train/trainer.py:53-56) — as:
+
+1. one GEMM into a bf16 logits buffer whose rows are padded to a multiple of
+   128 columns, so every row is 16-byte aligned although V = 50257 is odd;
+2. one HIP kernel that reads each logits row once, produces the per-row loss
+   and overwrites the row with ``(softmax - onehot) / n_valid`` — the gradient
+   with respect to the logits is already in place when backward starts;
+3. in backward, the two GEMMs for ``dhidden`` and ``dweight``.
+
+fp32 logits (1.65 GB at B=8, T=1024 for GPT-2) are never materialised.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .. import _ext
+
+_PAD = 128
+
+
+def cross_entropy_reference(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = -100):
+    return F.cross_entropy(logits.float().view(-1, logits.shape[-1]), targets.view(-1),
+                           ignore_index=ignore_index)
+
+
+def lm_head_cross_entropy_reference(hidden, weight, targets, ignore_index=-100):
+    logits = F.linear(hidden, weight)
+    return cross_entropy_reference(logits, targets, ignore_index)
+
+
+def _padded_cols(v: int) -> int:
+    return (v + _PAD - 1) // _PAD * _PAD
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """Cross-entropy over given logits; the logits buffer is consumed (overwritten)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        ext = _ext.require()
+        V = logits.shape[-1]
+        rows = logits.numel() // V
+        vp = _padded_cols(V)
+        if logits.is_contiguous() and V == vp:
+            buf = logits.view(rows, V)
+        else:
+            buf = torch.empty(rows, vp, dtype=logits.dtype, device=logits.device)[:, :V]
+            buf.copy_(logits.reshape(rows, V))
+        tgt = targets.reshape(-1).contiguous()
+        n_valid = (tgt != ignore_index).sum().clamp_(min=1).to(torch.float32)
+        scale = n_valid.reciprocal().reshape(1)
+        row_loss = ext.cross_entropy_fwd_bwd(buf, tgt, V, scale, ignore_index)
+        ctx.save_for_backward(buf)
+        ctx.shape = logits.shape
+        return row_loss.sum() * scale[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return (dlogits * dloss).reshape(ctx.shape), None, None
+
+
+class _LMHeadCrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, weight, targets, ignore_index):
+        ext = _ext.require()
+        V, d = weight.shape
+        h2 = hidden.reshape(-1, d)
+        rows = h2.shape[0]
+        vp = _padded_cols(V)
+        logits = torch.empty(rows, vp, dtype=hidden.dtype, device=hidden.device)
+        torch.mm(h2, weight.t(), out=logits[:, :V])
+        tgt = targets.reshape(-1).contiguous()
+        n_valid = (tgt != ignore_index).sum().clamp_(min=1).to(torch.float32)
+        scale = n_valid.reciprocal().reshape(1)
+        row_loss = ext.cross_entropy_fwd_bwd(logits[:, :V], tgt, V, scale, ignore_index)
+        ctx.save_for_backward(logits, h2, weight)
+        ctx.hidden_shape = hidden.shape
+        return row_loss.sum() * scale[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dlogits_p, h2, weight = ctx.saved_tensors
+        V = weight.shape[0]
+        dlogits = dlogits_p[:, :V]
+        dhidden = dweight = None
+        if ctx.needs_input_grad[0]:
+            dhidden = torch.mm(dlogits, weight).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
+        if ctx.needs_input_grad[1]:
+            dweight = torch.mm(dlogits.t(), h2).mul_(dloss.to(weight.dtype))
+        return dhidden, dweight, None, None
+
+
+def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Mean cross-entropy of ``logits[..., V]`` against integer ``targets``."""
+    if _ext.use_hip(logits):
+        return _CrossEntropyFn.apply(logits, targets, ignore_index)
+    return cross_entropy_reference(logits, targets, ignore_index)
+
+
+def lm_head_cross_entropy(hidden: torch.Tensor, weight: torch.Tensor, targets: torch.Tensor,
+                          ignore_index: int = -100) -> torch.Tensor:
+    """``cross_entropy(hidden @ weight.T, targets)`` without fp32 / unpadded logits."""
+    if _ext.use_hip(hidden):
+        return _LMHeadCrossEntropyFn.apply(hidden, weight, targets, ignore_index)
+    return lm_head_cross_entropy_reference(hidden, weight, targets, ignore_index)

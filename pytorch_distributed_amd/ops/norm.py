@@ -1,0 +1,88 @@
+"""LayerNorm / RMSNorm with the residual add fused in.
+
+``fused_add_layer_norm(x, residual, weight, bias, eps)`` returns
+``(LN(x + residual), x + residual)``: the normalised activation for the next
+GEMM and the updated residual stream, produced by one kernel that reads each
+row once. In the backward the gradient arriving through the residual stream
+is added inside the LayerNorm-backward kernel, so a pre-norm transformer block
+(reference: assignments/assignment1/model/my_gpt2.py:121-134) runs without any
+stand-alone elementwise add.
+
+GPU tensors run the gfx950 kernels of ``csrc/kernels/norm.hip``; CPU tensors
+(and ``PDA_FORCE_REFERENCE=1``) run the PyTorch reference below, which is also
+the oracle of the kernel parity tests.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import _ext
+
+
+# --------------------------------------------------------------------------- reference
+def layer_norm_reference(x, residual, weight, bias, eps):
+    h = x if residual is None else x + residual
+    y = F.layer_norm(h.float(), (h.shape[-1],), weight.float(), bias.float(), eps).to(h.dtype)
+    return y, h
+
+
+def rms_norm_reference(x, residual, weight, eps):
+    h = x if residual is None else x + residual
+    hf = h.float()
+    y = hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps) * weight.float()
+    return y.to(h.dtype), h
+
+
+# --------------------------------------------------------------------------- HIP path
+class _FusedNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, rms):
+        ext = _ext.require()
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        y, h, mean, rstd = ext.norm_forward(x, res, weight, bias, eps, rms)
+        if res is None:
+            h = x
+        ctx.rms = rms
+        ctx.has_residual = res is not None
+        ctx.save_for_backward(h, weight, mean if not rms else None, rstd)
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, not as zeros
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, dh):
+        ext = _ext.require()
+        h, weight, mean, rstd = ctx.saved_tensors
+        if dy is None:  # only the residual stream was consumed downstream
+            return dh, (dh if ctx.has_residual else None), None, None, None, None
+        dy = dy.contiguous()
+        dres = dh.contiguous() if dh is not None else None
+        dx, dw, db = ext.norm_backward(dy, h, weight, mean, rstd, dres, ctx.rms)
+        return dx, (dx if ctx.has_residual else None), dw, (None if ctx.rms else db), None, None
+
+
+def fused_add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                         bias: torch.Tensor, eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns ``(layer_norm(x + residual), x + residual)`` (``residual`` may be None)."""
+    if _ext.use_hip(x):
+        return _FusedNormFn.apply(x, residual, weight, bias, eps, False)
+    return layer_norm_reference(x, residual, weight, bias, eps)
+
+
+def fused_add_rms_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                       eps: float = 1e-6) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns ``(rms_norm(x + residual), x + residual)`` (``residual`` may be None)."""
+    if _ext.use_hip(x):
+        return _FusedNormFn.apply(x, residual, weight, None, eps, True)
+    return rms_norm_reference(x, residual, weight, eps)
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    return fused_add_layer_norm(x, None, weight, bias, eps)[0]
+
+
+def rms_norm(x, weight, eps=1e-6):
+    return fused_add_rms_norm(x, None, weight, eps)[0]

@@ -1,0 +1,255 @@
+"""Single-process training loop: gradient accumulation, logging, checkpoints.
+
+Constructor arguments, the ``train(dataloader, profiler)`` / ``save_checkpoint`` /
+``load_checkpoint`` surface, the log line
+``step={n} | loss={:.4f} | lr={:.2e} | time={:.1f}s`` and the checkpoint dictionary
+``{model_state_dict, optimizer_state_dict, step[, lr_scheduler_state_dict]}`` follow the
+reference trainer (assignments/assignment1/train/trainer.py:10-21,93-98,117-141).
+
+The loop itself is arranged for a GPU that should never wait for the host:
+
+* the loss of every micro-batch is accumulated in a device tensor and only read back
+  (one ``.item()``) on logging steps — the reference synchronises on every micro-batch
+  (trainer.py:79);
+* when the model supports it, ``model(inputs, targets)`` returns the loss through the
+  fused LM-head + cross-entropy op instead of materialising logits;
+* with :class:`~pytorch_distributed_amd.optim.FusedAdamW` the gradients are cleared
+  inside the optimizer kernel;
+* throughput (tokens/s, MFU against the MI355X dense bf16 peak) is appended to the log
+  line and optionally written as JSON lines.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import os
+import time
+from pathlib import Path
+from typing import Any, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..optim import FusedAdamW
+from ..utils.flops import model_flops_per_token, mfu
+
+
+def unwrap_model(model: nn.Module) -> nn.Module:
+    """Strips data-parallel wrappers (anything exposing ``.module``)."""
+    while hasattr(model, "module") and isinstance(getattr(model, "module"), nn.Module):
+        model = model.module
+    return model
+
+
+class Trainer:
+    def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, lr_scheduler: Optional[Any] = None,
+                 max_steps: int = 1000, global_batch_size: int = 32, micro_batch_size: int = 8,
+                 log_every_n_steps: int = 10, save_every_n_steps: Optional[int] = None,
+                 checkpoint_dir: str = "checkpoints", metrics_file: Optional[str] = None):
+        self.model = model
+        self.optimizer = optimizer
+        self.lr_scheduler = lr_scheduler
+        self.max_steps = max_steps
+        self.global_batch_size = global_batch_size
+        self.micro_batch_size = micro_batch_size
+        self.log_every_n_steps = log_every_n_steps
+        self.save_every_n_steps = save_every_n_steps
+        self.checkpoint_dir = checkpoint_dir
+        self.metrics_file = metrics_file
+        self.world_size = 1
+        self.rank = 0
+
+        if global_batch_size % micro_batch_size != 0:
+            raise ValueError(f"Global batch size ({global_batch_size}) must be divisible by "
+                             f"micro batch size ({micro_batch_size})")
+        self.grad_accumulation_steps = global_batch_size // micro_batch_size
+
+        self.current_step = 0
+        self.batch_count = 0
+        self.loss_accumulator = None  # device tensor, created on first use
+        self.start_time = None
+        self._tokens_since_log = 0
+        self._time_of_last_log = None
+
+        if save_every_n_steps is not None:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+
+        base = unwrap_model(model)
+        try:
+            self._fused_loss = "targets" in inspect.signature(base.forward).parameters
+        except (TypeError, ValueError):
+            self._fused_loss = False
+        self._flops_per_token = None
+
+    # ------------------------------------------------------------------ one micro-batch
+    def _loss(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        if self._fused_loss:
+            return self.model(inputs, targets)
+        logits = self.model(inputs)
+        return ops.cross_entropy(logits.view(-1, logits.size(-1)), targets.view(-1))
+
+    def training_step(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """Forward + backward of one micro-batch; returns the (unscaled) loss, detached."""
+        loss = self._loss(inputs, targets)
+        (loss / self.grad_accumulation_steps).backward()
+        return loss.detach()
+
+    # ------------------------------------------------------------------ helpers
+    def _accumulate_loss(self, loss: torch.Tensor) -> None:
+        if self.loss_accumulator is None:
+            self.loss_accumulator = torch.zeros((), dtype=torch.float32, device=loss.device)
+        self.loss_accumulator += loss.float()
+
+    def _optimizer_step(self) -> None:
+        if isinstance(self.optimizer, FusedAdamW):
+            self.optimizer.step(zero_grad=True)
+        else:
+            self.optimizer.step()
+        self.optimizer.zero_grad()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+
+    def _current_lr(self) -> float:
+        if self.lr_scheduler is not None:
+            return self.lr_scheduler.get_last_lr()[0]
+        return self.optimizer.param_groups[0]["lr"]
+
+    def _elapsed(self) -> float:
+        return time.time() - self.start_time
+
+    def _throughput_fields(self, device) -> dict:
+        """tokens/s and MFU since the previous log line (whole job)."""
+        now = time.time()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+            now = time.time()
+        fields = {}
+        if self._time_of_last_log is not None and now > self._time_of_last_log and self._tokens_since_log:
+            tps = self._tokens_since_log / (now - self._time_of_last_log)
+            fields["tok/s"] = tps
+            if self._flops_per_token is None:
+                self._flops_per_token = model_flops_per_token(unwrap_model(self.model), self._seq_len)
+            if self._flops_per_token:
+                fields["mfu"] = mfu(tps, self._flops_per_token, self.world_size)
+        if device.type == "cuda":
+            fields["mem_gb"] = torch.cuda.max_memory_allocated(device) / 2**30
+        self._time_of_last_log = now
+        self._tokens_since_log = 0
+        return fields
+
+    def _log(self, loss_value: float, device) -> None:
+        extra = self._throughput_fields(device)
+        line = (f"step={self.current_step} | loss={loss_value:.4f} | lr={self._current_lr():.2e} | "
+                f"time={self._elapsed():.1f}s")
+        if "tok/s" in extra:
+            line += f" | tok/s={extra['tok/s']:.0f}"
+        if "mfu" in extra:
+            line += f" | mfu={100 * extra['mfu']:.1f}%"
+        if "mem_gb" in extra:
+            line += f" | mem={extra['mem_gb']:.1f}GB"
+        if self.rank == 0:
+            print(line, flush=True)
+            if self.metrics_file:
+                with open(self.metrics_file, "a") as f:
+                    f.write(json.dumps({"step": self.current_step, "loss": loss_value, "lr": self._current_lr(),
+                                        "time_s": self._elapsed(), **extra}) + "\n")
+
+    def _aggregate_loss(self, loss: float, device) -> float:
+        return loss
+
+    def _maybe_checkpoint(self) -> None:
+        if (self.save_every_n_steps is not None and self.current_step > 0
+                and self.current_step % self.save_every_n_steps == 0):
+            path = f"{self.checkpoint_dir}/checkpoint_step_{self.current_step}.pt"
+            self.save_checkpoint(path)
+            if self.rank == 0:
+                print(f"Saved: {path}")
+
+    # ------------------------------------------------------------------ main loop
+    def _sync_flag(self, is_last_microbatch: bool):
+        """Hook for the distributed trainer (gradient synchronisation only on the last micro-batch)."""
+        return None
+
+    def train(self, dataloader, profiler: Optional[Any] = None) -> None:
+        self.model.train()
+        self.start_time = time.time()
+        self._time_of_last_log = None
+        if self.rank == 0:
+            print(f"Starting training for {self.max_steps} steps")
+        if self.grad_accumulation_steps < 1:
+            raise ValueError("gradient accumulation steps must be >= 1 "
+                             "(global batch smaller than micro batch x world size?)")
+
+        for inputs, targets in dataloader:
+            if self.current_step >= self.max_steps:
+                break
+            device = inputs.device
+            self._seq_len = inputs.shape[1]
+            if self._time_of_last_log is None:
+                self._time_of_last_log = time.time()
+
+            is_last_microbatch = (self.batch_count + 1) % self.grad_accumulation_steps == 0
+            loss = self._run_micro_batch(inputs, targets, is_last_microbatch)
+            self._accumulate_loss(loss)
+            self._tokens_since_log += inputs.numel() * self.world_size
+            self.batch_count += 1
+
+            if is_last_microbatch:
+                self._optimizer_step()
+                if self.current_step % self.log_every_n_steps == 0:
+                    avg = float(self.loss_accumulator.item()) / self.grad_accumulation_steps  # only host sync
+                    self._log(self._aggregate_loss(avg, device), device)
+                self._maybe_checkpoint()
+                self.loss_accumulator.zero_()
+                self.current_step += 1
+
+            if profiler is not None:
+                profiler.step()
+
+        if self.rank == 0:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            print(f"Training completed in {self._elapsed():.1f}s")
+
+    def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:
+        return self.training_step(inputs, targets)
+
+    # ------------------------------------------------------------------ checkpoints
+    def _model_state_dict(self):
+        return self.model.state_dict()
+
+    def _optimizer_state_dict(self):
+        return self.optimizer.state_dict()
+
+    def save_checkpoint(self, path: Union[str, Path]) -> None:
+        checkpoint = {
+            "model_state_dict": self._model_state_dict(),
+            "optimizer_state_dict": self._optimizer_state_dict(),
+            "step": self.current_step,
+        }
+        if self.lr_scheduler is not None:
+            checkpoint["lr_scheduler_state_dict"] = self.lr_scheduler.state_dict()
+        if self.rank == 0:
+            tmp = f"{path}.tmp{os.getpid()}"
+            torch.save(checkpoint, tmp)
+            os.replace(tmp, path)
+
+    def load_checkpoint(self, path: Union[str, Path]) -> None:
+        device = getattr(self.model, "device", None) or next(self.model.parameters()).device
+        checkpoint = torch.load(path, map_location=device, weights_only=True)
+        state = checkpoint["model_state_dict"]
+        state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state.items()}
+        self._load_model_state(state)
+        self._load_optimizer_state(checkpoint["optimizer_state_dict"])
+        self.current_step = checkpoint.get("step", 0)
+        if self.lr_scheduler is not None and "lr_scheduler_state_dict" in checkpoint:
+            self.lr_scheduler.load_state_dict(checkpoint["lr_scheduler_state_dict"])
+        if self.rank == 0:
+            print(f"Loaded checkpoint from step {self.current_step}")
+
+    def _load_model_state(self, state) -> None:
+        self.model.load_state_dict(state)
+
+    def _load_optimizer_state(self, state) -> None:
+        self.optimizer.load_state_dict(state)

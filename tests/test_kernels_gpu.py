@@ -1,0 +1,226 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+
+from pytorch_distributed_amd import _ext, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ext_loaded():
+    return _ext.require()
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+# --------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("d", [768, 1024, 1280, 1600, 4096])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_fwd_bwd(d, dtype, with_res):
+    _ext_loaded()
+    torch.manual_seed(0)
+    rows = 517  # odd on purpose: exercises the row tail
+    x = torch.randn(rows, d, device=DEV, dtype=dtype)
+    res = torch.randn(rows, d, device=DEV, dtype=dtype) if with_res else None
+    w = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(d, device=DEV)).to(dtype)
+    dy = torch.randn(rows, d, device=DEV, dtype=dtype)
+    dh = torch.randn(rows, d, device=DEV, dtype=dtype)
+
+    def run(fn, xs):
+        leaves = [t.detach().clone().requires_grad_(True) if t is not None else None for t in xs]
+        y, h = fn(leaves[0], leaves[1], leaves[2], leaves[3], 1e-5)
+        (y.float() * dy.float()).sum().add((h.float() * dh.float()).sum()).backward()
+        return y, h, [t.grad if t is not None else None for t in leaves]
+
+    y, h, g = run(ops.fused_add_layer_norm, [x, res, w, b])
+    # fp32 oracle on the same (already rounded) inputs
+    xs32 = [t.float() if t is not None else None for t in (x, res, w, b)]
+    y_ref, h_ref, g_ref = run(ops.layer_norm_reference, xs32)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(y, y_ref) < tol
+    assert rel_err(h, h_ref) < tol
+    for a, r in zip(g, g_ref):
+        if a is not None:
+            assert rel_err(a, r) < tol, (d, dtype, with_res)
+
+
+@pytest.mark.parametrize("d", [256, 2048, 4096])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rmsnorm_fwd_bwd(d, dtype):
+    _ext_loaded()
+    torch.manual_seed(1)
+    rows = 300
+    x = torch.randn(rows, d, device=DEV, dtype=dtype)
+    res = torch.randn(rows, d, device=DEV, dtype=dtype)
+    w = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    dy = torch.randn(rows, d, device=DEV, dtype=dtype)
+
+    def run(fn, xs):
+        leaves = [t.detach().clone().requires_grad_(True) for t in xs]
+        y, h = fn(leaves[0], leaves[1], leaves[2], 1e-6)
+        (y.float() * dy.float()).sum().add(h.float().sum()).backward()
+        return y, h, [t.grad for t in leaves]
+
+    y, h, g = run(ops.fused_add_rms_norm, [x, res, w])
+    y_ref, h_ref, g_ref = run(ops.rms_norm_reference, [x.float(), res.float(), w.float()])
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(y, y_ref) < tol and rel_err(h, h_ref) < tol
+    for a, r in zip(g, g_ref):
+        assert rel_err(a, r) < tol
+
+
+# --------------------------------------------------------------------------- activations
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n", [8 * 1024 * 5120 // 64, 1000003])
+def test_gelu(dtype, n):
+    _ext_loaded()
+    torch.manual_seed(2)
+    u = (3 * torch.randn(n, device=DEV)).to(dtype)
+    dy = torch.randn(n, device=DEV, dtype=dtype)
+    a = u.clone().requires_grad_(True)
+    y = ops.gelu_new(a)
+    y.backward(dy)
+    r = u.float().requires_grad_(True)
+    y_ref = ops.gelu_new_reference(r)
+    y_ref.backward(dy.float())
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-6
+    assert rel_err(y, y_ref) < tol
+    assert rel_err(a.grad, r.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_swiglu(dtype):
+    _ext_loaded()
+    torch.manual_seed(3)
+    x = (2 * torch.randn(333, 2 * 1376, device=DEV)).to(dtype)
+    dy = torch.randn(333, 1376, device=DEV, dtype=dtype)
+    a = x.clone().requires_grad_(True)
+    y = ops.swiglu(a)
+    y.backward(dy)
+    r = x.float().requires_grad_(True)
+    y_ref = ops.swiglu_reference(r)
+    y_ref.backward(dy.float())
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-6
+    assert rel_err(y, y_ref) < tol
+    assert rel_err(a.grad, r.grad) < tol
+
+
+# --------------------------------------------------------------------------- cross entropy
+@pytest.mark.parametrize("vocab", [50257, 32000, 512, 131071])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cross_entropy_logits(vocab, dtype):
+    _ext_loaded()
+    torch.manual_seed(4)
+    rows = 257
+    logits = (4 * torch.randn(rows, vocab, device=DEV)).to(dtype)
+    targets = torch.randint(0, vocab, (rows,), device=DEV)
+    targets[::7] = -100
+    a = logits.clone().requires_grad_(True)
+    loss = ops.cross_entropy(a, targets)
+    (loss * 0.5).backward()
+    r = logits.float().requires_grad_(True)
+    loss_ref = ops.cross_entropy_reference(r, targets)
+    (loss_ref * 0.5).backward()
+    assert abs(loss.item() - loss_ref.item()) < (2e-3 if dtype == torch.bfloat16 else 1e-5) * max(1.0, abs(loss_ref.item()))
+    assert rel_err(a.grad, r.grad) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("vocab,d", [(50257, 768), (1000, 256)])
+def test_lm_head_cross_entropy(vocab, d):
+    _ext_loaded()
+    torch.manual_seed(5)
+    rows = 512
+    h = torch.randn(rows, d, device=DEV, dtype=torch.bfloat16)
+    w = (0.05 * torch.randn(vocab, d, device=DEV)).to(torch.bfloat16)
+    targets = torch.randint(0, vocab, (rows,), device=DEV)
+    ha, wa = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    loss = ops.lm_head_cross_entropy(ha, wa, targets)
+    loss.backward()
+    hr, wr = h.float().requires_grad_(True), w.float().requires_grad_(True)
+    loss_ref = ops.lm_head_cross_entropy_reference(hr, wr, targets)
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 5e-3 * abs(loss_ref.item())
+    assert rel_err(ha.grad, hr.grad) < 2e-2
+    assert rel_err(wa.grad, wr.grad) < 2e-2
+
+
+# --------------------------------------------------------------------------- AdamW
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_adamw_matches_torch(dtype):
+    _ext_loaded()
+    from pytorch_distributed_amd.optim import FusedAdamW
+
+    torch.manual_seed(6)
+    shapes = [(1 << 21,), (1023, 7), (50257, 64), (5,), (1280,), (3, 3, 3)]
+    ref_params = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    params = [p.detach().to(dtype).clone().requires_grad_(True) for p in ref_params]
+    if dtype == torch.bfloat16:  # the fp32 reference starts from the rounded values too
+        ref_params = [p.detach().float().clone().requires_grad_(True) for p in params]
+    opt = FusedAdamW(params, lr=3e-4, weight_decay=0.1)
+    ref = torch.optim.AdamW(ref_params, lr=3e-4, weight_decay=0.1)
+    for step in range(5):
+        for p, r in zip(params, ref_params):
+            g = torch.randn_like(r)
+            r.grad = g.clone()
+            p.grad = g.to(dtype)
+            if dtype == torch.bfloat16:
+                r.grad = p.grad.float()
+        opt.step(zero_grad=(step % 2 == 0))
+        ref.step()
+        if step % 2 == 0:
+            assert all(float(p.grad.abs().max()) == 0.0 for p in params)
+    for p, r in zip(params, ref_params):
+        master = opt.state[p].get("master", p.data)
+        assert rel_err(master, r) < 1e-6
+        assert rel_err(opt.state[p]["exp_avg"], ref.state[r]["exp_avg"]) < 1e-5
+        assert rel_err(opt.state[p]["exp_avg_sq"], ref.state[r]["exp_avg_sq"]) < 1e-5
+        if dtype == torch.bfloat16:
+            assert torch.equal(p.data, master.to(torch.bfloat16))
+
+
+# --------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,T,H,D", [(2, 1024, 4, 64), (1, 333, 3, 64), (2, 128, 2, 128), (1, 640, 2, 128),
+                                     (1, 64, 1, 64), (3, 1000, 5, 64)])
+def test_attention_forward(B, T, H, D):
+    ext = _ext_loaded()
+    torch.manual_seed(7)
+    qkv = torch.randn(B, T, 3 * H * D, device=DEV, dtype=torch.bfloat16)
+    out, lse = ext.attention_forward(qkv, H, 1.0 / math.sqrt(D))
+    ref = ops.attention_reference(qkv.float(), H)
+    assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
+    q, k, _ = qkv.float().view(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(D)
+    s = s.masked_fill(~torch.ones(T, T, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+    assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 2e-2
+
+
+def test_attention_forward_structured():
+    """Exact-integer check of the MFMA operand maps: V carries an asymmetric pattern and
+    attention is made (near) one-hot, so a swapped row/column or a permuted k order cannot pass."""
+    ext = _ext_loaded()
+    B, T, H, D = 1, 256, 2, 64
+    q = torch.zeros(B, T, H, D, device=DEV)
+    k = torch.zeros(B, T, H, D, device=DEV)
+    t = torch.arange(T, device=DEV)
+    # query t attends (with a huge logit) to key max(t - 3, 0): near one-hot rows.
+    tgt = (t - 3).clamp(min=0)
+    # position p is encoded as a +-1 code of 8 bits in the first 8 dims; q carries the code of
+    # its target key scaled up, so the matching key wins the softmax by a wide margin
+    bits = ((t[:, None] >> torch.arange(8, device=DEV)) & 1).float() * 2 - 1  # [T, 8]
+    k[0, :, :, :8] = bits[:, None, :]
+    q[0, :, :, :8] = bits[tgt][:, None, :] * 24.0
+    v = (t[:, None, None] * 1.0 + torch.arange(D, device=DEV)[None, None, :] * 0.25 +
+         torch.arange(H, device=DEV)[None, :, None] * 1000.0).expand(T, H, D)[None]
+    qkv = torch.stack([q, k, v.contiguous()], dim=2).reshape(B, T, 3 * H * D).to(torch.bfloat16)
+    out, _ = ext.attention_forward(qkv, H, 1.0)
+    ref = ops.attention_reference(qkv.float(), H, scale=1.0)
+    assert (out.float() - ref).abs().max().item() <= 8.0  # bf16 resolution at magnitude ~1000-2000
+    assert rel_err(out, ref) < 5e-3
