@@ -5,7 +5,7 @@
 // launched on operands the kernels were not written for), allocates outputs
 // through the caching allocator, and launches on the current HIP stream.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -31,6 +31,8 @@ void check_gpu(const at::Tensor& t, const char* name) {
   TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, " must be 16-byte aligned");
 }
 
+// Kernels launch on PyTorch's current stream of the current device (set by the DeviceGuard
+// each binding takes on its first tensor argument).
 hipStream_t current_stream() { return c10::hip::getCurrentHIPStream().stream(); }
 
 void check_launch(const char* what) {
@@ -44,7 +46,7 @@ std::vector<at::Tensor> norm_forward(const at::Tensor& x, const std::optional<at
                                      double eps, bool rms) {
   check_gpu(x, "x");
   check_gpu(weight, "weight");
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::DeviceGuard guard(x.device());
   const int64_t d = x.size(-1);
   const int64_t rows = x.numel() / d;
   const auto dt = dtype_of(x);
@@ -87,7 +89,7 @@ std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
   check_gpu(x, "x");
   check_gpu(weight, "weight");
   check_gpu(rstd, "rstd");
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::DeviceGuard guard(x.device());
   const int64_t d = x.size(-1);
   const int64_t rows = x.numel() / d;
   const auto dt = dtype_of(x);
@@ -131,7 +133,7 @@ std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
 // ------------------------------------------------------------ activations --
 at::Tensor gelu_forward(const at::Tensor& u) {
   check_gpu(u, "u");
-  const c10::hip::HIPGuard guard(u.device());
+  const c10::DeviceGuard guard(u.device());
   at::Tensor y = at::empty_like(u);
   pda::gelu_forward(dtype_of(u), u.data_ptr(), y.data_ptr(), u.numel(), current_stream());
   check_launch("gelu_forward");
@@ -142,7 +144,7 @@ at::Tensor gelu_backward(const at::Tensor& dy, const at::Tensor& u) {
   check_gpu(dy, "dy");
   check_gpu(u, "u");
   TORCH_CHECK(dy.sizes() == u.sizes() && dy.scalar_type() == u.scalar_type(), "gelu: dy must match u");
-  const c10::hip::HIPGuard guard(u.device());
+  const c10::DeviceGuard guard(u.device());
   at::Tensor du = at::empty_like(u);
   pda::gelu_backward(dtype_of(u), dy.data_ptr(), u.data_ptr(), du.data_ptr(), u.numel(), current_stream());
   check_launch("gelu_backward");
@@ -151,7 +153,7 @@ at::Tensor gelu_backward(const at::Tensor& dy, const at::Tensor& u) {
 
 at::Tensor swiglu_forward(const at::Tensor& x) {
   check_gpu(x, "x");
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::DeviceGuard guard(x.device());
   const int64_t f2 = x.size(-1);
   const auto dt = dtype_of(x);
   const int vec = dt == pda::kBF16 ? 8 : 4;
@@ -167,7 +169,7 @@ at::Tensor swiglu_forward(const at::Tensor& x) {
 at::Tensor swiglu_backward(const at::Tensor& dy, const at::Tensor& x) {
   check_gpu(dy, "dy");
   check_gpu(x, "x");
-  const c10::hip::HIPGuard guard(x.device());
+  const c10::DeviceGuard guard(x.device());
   const int64_t f2 = x.size(-1);
   const auto dt = dtype_of(x);
   const int vec = dt == pda::kBF16 ? 8 : 4;
@@ -199,7 +201,7 @@ at::Tensor cross_entropy_fwd_bwd(at::Tensor logits, const at::Tensor& targets, i
   const int64_t end_byte = (logits.storage_offset() + (rows - 1) * ld + ld) * elt;
   TORCH_CHECK(rows == 0 || end_byte <= (int64_t)logits.storage().nbytes(),
               "ce: padded rows run past the end of the logits storage");
-  const c10::hip::HIPGuard guard(logits.device());
+  const c10::DeviceGuard guard(logits.device());
   at::Tensor row_loss = at::empty({rows}, logits.options().dtype(at::kFloat));
   pda::cross_entropy_fwd_bwd(dtype_of(logits), logits.data_ptr(), targets.data_ptr<int64_t>(),
                              row_loss.data_ptr<float>(), grad_scale.data_ptr<float>(), rows, (int)vocab,
@@ -218,7 +220,7 @@ void adamw_step(const std::vector<at::Tensor>& params, const std::vector<std::op
               "adamw: list lengths differ");
   if (n == 0) return;
   TORCH_CHECK(step >= 1, "adamw: step counts from 1");
-  const c10::hip::HIPGuard guard(params[0].device());
+  const c10::DeviceGuard guard(params[0].device());
   std::vector<pda::AdamWTensor> ts;
   ts.reserve(n);
   const pda::DType gdt = dtype_of(grads[0]);
@@ -267,7 +269,7 @@ void accumulate_bf16_into_f32(const at::Tensor& src, at::Tensor dst, double scal
   TORCH_CHECK(src.scalar_type() == at::kBFloat16 && dst.scalar_type() == at::kFloat &&
                   src.numel() == dst.numel(),
               "accumulate: expected bf16 src and float32 dst of equal size");
-  const c10::hip::HIPGuard guard(src.device());
+  const c10::DeviceGuard guard(src.device());
   pda::accumulate_bf16_into_f32(src.data_ptr(), dst.data_ptr<float>(), src.numel(), (float)scale,
                                 current_stream());
   check_launch("accumulate_bf16_into_f32");
@@ -283,7 +285,7 @@ std::vector<at::Tensor> attention_forward(const at::Tensor& qkv, int64_t num_hea
   const int64_t D = three_hd / (3 * num_heads);
   TORCH_CHECK(D == 64 || D == 128, "attention: head_dim must be 64 or 128, got ", D);
   TORCH_CHECK(T >= 1 && B >= 1, "attention: empty input");
-  const c10::hip::HIPGuard guard(qkv.device());
+  const c10::DeviceGuard guard(qkv.device());
   at::Tensor out = at::empty({B, T, num_heads * D}, qkv.options());
   at::Tensor lse = at::empty({B, num_heads, T}, qkv.options().dtype(at::kFloat));
   pda::attention_forward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)T,
@@ -307,10 +309,12 @@ at::Tensor attention_backward(const at::Tensor& qkv, const at::Tensor& out, cons
   TORCH_CHECK(out.numel() == B * T * num_heads * D && dout.numel() == out.numel() &&
                   lse.numel() == B * num_heads * T,
               "attention backward: shape mismatch");
-  const c10::hip::HIPGuard guard(qkv.device());
+  const c10::DeviceGuard guard(qkv.device());
   at::Tensor dqkv = at::empty_like(qkv);
   at::Tensor delta = at::empty_like(lse);
-  TORCH_CHECK(false, "attention_backward: kernel not built yet");
+  pda::attention_backward(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(),
+                          delta.data_ptr<float>(), dqkv.data_ptr(), (int)B, (int)T, (int)num_heads,
+                          (int)D, (float)softmax_scale, current_stream());
   check_launch("attention_backward");
   return dqkv;
 }

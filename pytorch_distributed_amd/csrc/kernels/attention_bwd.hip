@@ -1,0 +1,356 @@
+// Causal attention backward for gfx950: two kernels, no atomics, no T x T tensor.
+//
+//   attn_bwd_dq_kernel    query-stationary. One workgroup = 128 queries (32 per wave),
+//                         walks the key tiles up to the diagonal like the forward:
+//                           S^T  = K . Q^T            (recompute, keys on registers)
+//                           P^T  = exp2(c S^T - LSE)  (the forward's LSE: no max, no sum)
+//                           dP^T = V . dO^T
+//                           dS^T = P^T (dP^T - delta)
+//                           dQ^T += K^T . dS^T        (K read transposed from LDS,
+//                                                      dS^T straight from registers)
+//                         Also produces delta = rowsum(dO * O) for the second kernel.
+//   attn_bwd_dkv_kernel   key-stationary. One workgroup = 128 keys (32 per wave, K and V
+//                         rows live in registers as MFMA B operands), walks the query
+//                         tiles from the diagonal to the end:
+//                           S  = Q . K^T - LSE/c   (row constant preloaded in the accumulator)
+//                           dP = dO . V^T - delta  (idem)
+//                           dV^T += dO^T . P ,  dK^T += Q^T . dS
+//                         Q and dO tiles are read by rows for S / dP and transposed for
+//                         dV / dK from ONE swizzled LDS image each.
+//
+// Both kernels keep the "free index on the lane" orientation of attention_common.h, so P
+// and dS feed the next MFMA from the accumulator registers and never pass through LDS.
+// dK and dV of a key are summed inside one wave and dQ of a query inside one wave, so the
+// result is deterministic. The price is recomputing S and dP in both kernels (7 matrix
+// products instead of 5); the alternative single-kernel form needs fp32 atomics for dQ.
+#include "attention_common.h"
+#include "pda_kernels.h"
+
+namespace pda {
+namespace {
+
+using namespace attn;
+
+constexpr int kThreads = 256;
+constexpr int kBM = 128;  // rows owned by a workgroup (queries in dq, keys in dkv)
+constexpr int kBN = 64;   // rows per streamed tile (keys in dq, queries in dkv)
+
+// ============================================================================ dQ
+template <int D>
+__global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(
+    const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ out,
+    const bf16_raw* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta_out,
+    bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale) {
+  constexpr int kKSteps = D / 16;
+  constexpr int kDBlocks = D / 32;
+  constexpr int kTileBytes = kBN * D * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int BH = B * H;
+  const int n_qt = (T + kBM - 1) / kBM;
+  const int bh = blockIdx.x % BH;
+  const int qt = n_qt - 1 - blockIdx.x / BH;
+  const int b = bh / H, head = bh % H;
+  const int64_t tok_stride = int64_t(3) * H * D;
+  const int64_t o_stride = int64_t(H) * D;
+  const bf16_raw* q_base = qkv + int64_t(b) * T * tok_stride + int64_t(head) * D;
+  const bf16_raw* k_base = q_base + int64_t(H) * D;
+  const bf16_raw* v_base = q_base + int64_t(2) * H * D;
+
+  const int q0 = qt * kBM + wave * 32;
+  const int q_row = q0 + r;
+  const int q_ld = q_row < T ? q_row : T - 1;
+
+  // Q and dO fragments (B operands), and delta = sum_d dO * O for this lane's query.
+  bf16x8 qf[kKSteps], dof[kKSteps];
+  float dpart = 0.f;
+  {
+    const bf16_raw* o_row = out + (int64_t(b) * T + q_ld) * o_stride + int64_t(head) * D;
+    const bf16_raw* do_row = dout + (int64_t(b) * T + q_ld) * o_stride + int64_t(head) * D;
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(q_base + int64_t(q_ld) * tok_stride + 16 * ks + 8 * h);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(do_row + 16 * ks + 8 * h);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(o_row + 16 * ks + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
+    }
+  }
+  const float delta = lane_pair_sum(dpart);
+  const float lse2 = lse[(int64_t(b) * H + head) * T + q_ld] * kLog2e;
+  if (h == 0 && q_row < T) delta_out[(int64_t(b) * H + head) * T + q_row] = delta;
+  const float c = scale * kLog2e;
+
+  f32x16 dq_acc[kDBlocks];
+#pragma unroll
+  for (int i = 0; i < kDBlocks; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dq_acc[i][j] = 0.f;
+
+  const int q_tile_end = min(qt * kBM + kBM, T);
+  const int n_tiles = (q_tile_end + kBN - 1) / kBN;
+  const int wave_last_tile = min(q0 + 31, T - 1) / kBN;
+  const bool wave_active = q0 < T;
+
+  TileStager<D, kBN, kThreads> k_stage, v_stage;
+  k_stage.load(k_base, tok_stride, 0, T - 1, tid);
+  v_stage.load(v_base, tok_stride, 0, T - 1, tid);
+  k_stage.store(smem, tid);
+  v_stage.store(smem + kTileBytes, tid);
+  __syncthreads();
+
+  for (int j = 0; j < n_tiles; ++j) {
+    const char* k_tile = smem + (j & 1) * 2 * kTileBytes;
+    const char* v_tile = k_tile + kTileBytes;
+    const bool has_next = j + 1 < n_tiles;
+    if (has_next) {
+      k_stage.load(k_base, tok_stride, (j + 1) * kBN, T - 1, tid);
+      v_stage.load(v_base, tok_stride, (j + 1) * kBN, T - 1, tid);
+    }
+
+    if (wave_active && j <= wave_last_tile) {  // wave-uniform
+      f32x16 s_acc[2], dp_acc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s_acc[kb][i] = 0.f;
+          dp_acc[kb][i] = -delta;  // row constant preloaded: the chain ends as dP - delta
+        }
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+          const bf16x8 kf = lds_read_b128(k_tile, tile_off<D>(kb * 32 + r, 2 * ks + h));
+          s_acc[kb] = mfma32(kf, qf[ks], s_acc[kb]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+          const bf16x8 vf = lds_read_b128(v_tile, tile_off<D>(kb * 32 + r, 2 * ks + h));
+          dp_acc[kb] = mfma32(vf, dof[ks], dp_acc[kb]);
+        }
+      }
+      const int key0 = j * kBN;
+      const bool diag = key0 + kBN - 1 > q0;  // wave-uniform
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = __builtin_amdgcn_exp2f(s_acc[kb][i] * c - lse2);
+          if (diag && key0 + kb * 32 + acc_row(i, h) > q_row) p = 0.f;
+          s_acc[kb][i] = p * dp_acc[kb][i];  // dS^T (without the softmax scale)
+        }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f32x16& a = s_acc[s >> 1];
+        const int o = 8 * (s & 1);
+        const bf16x8 dsf = pack_acc8(a[o], a[o + 1], a[o + 2], a[o + 3], a[o + 4], a[o + 5], a[o + 6], a[o + 7]);
+#pragma unroll
+        for (int db = 0; db < kDBlocks; ++db) {
+          const bf16x8 ktf = tr_fragment<D>(k_tile, s, db, lane);
+          dq_acc[db] = mfma32(ktf, dsf, dq_acc[db]);
+        }
+      }
+    }
+
+    if (has_next) {
+      char* nk = smem + ((j + 1) & 1) * 2 * kTileBytes;
+      k_stage.store(nk, tid);
+      v_stage.store(nk + kTileBytes, tid);
+    }
+    __syncthreads();
+  }
+
+  if (q_row < T) {
+    bf16_raw* dq_row = dqkv + (int64_t(b) * T + q_row) * tok_stride + int64_t(head) * D;
+#pragma unroll
+    for (int db = 0; db < kDBlocks; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w = {pack_bf16x2(dq_acc[db][4 * g] * scale, dq_acc[db][4 * g + 1] * scale),
+                   pack_bf16x2(dq_acc[db][4 * g + 2] * scale, dq_acc[db][4 * g + 3] * scale)};
+        *reinterpret_cast<u32x2*>(dq_row + db * 32 + 8 * g + 4 * h) = w;
+      }
+  }
+}
+
+// ========================================================================= dK / dV
+template <int D>
+__global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
+    const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale) {
+  constexpr int kKSteps = D / 16;
+  constexpr int kDBlocks = D / 32;
+  constexpr int kTileBytes = kBN * D * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const int BH = B * H;
+  const int bh = blockIdx.x % BH;
+  const int kt = blockIdx.x / BH;  // key block 0 sees every query: heaviest first
+  const int b = bh / H, head = bh % H;
+  const int64_t tok_stride = int64_t(3) * H * D;
+  const int64_t o_stride = int64_t(H) * D;
+  const bf16_raw* q_base = qkv + int64_t(b) * T * tok_stride + int64_t(head) * D;
+  const bf16_raw* k_base = q_base + int64_t(H) * D;
+  const bf16_raw* v_base = q_base + int64_t(2) * H * D;
+  const bf16_raw* do_base = dout + int64_t(b) * T * o_stride + int64_t(head) * D;
+  const float* lse_row = lse + (int64_t(b) * H + head) * T;
+  const float* delta_row = delta + (int64_t(b) * H + head) * T;
+
+  const int key0 = kt * kBM + wave * 32;  // first key of this wave
+  const int key = key0 + r;               // this lane's key
+  const int key_ld = key < T ? key : T - 1;
+  const bool wave_active = key0 < T;
+
+  // K and V rows as B operands: lane (key r, h) holds row[16*ks + 8*h .. +7].
+  bf16x8 kf[kKSteps], vf[kKSteps];
+#pragma unroll
+  for (int ks = 0; ks < kKSteps; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(k_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(v_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
+  }
+  f32x16 dk_acc[kDBlocks], dv_acc[kDBlocks];
+#pragma unroll
+  for (int i = 0; i < kDBlocks; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      dk_acc[i][j] = 0.f;
+      dv_acc[i][j] = 0.f;
+    }
+  const float c = scale * kLog2e;
+  const float inv_scale = 1.f / scale;  // LSE (natural log of sum exp(scale*S)) in raw-score units
+
+  // Query tiles: from the one holding the workgroup's first key to the end.
+  const int first_tile = (kt * kBM) / kBN;
+  const int n_tiles = (T + kBN - 1) / kBN;
+
+  TileStager<D, kBN, kThreads> q_stage, do_stage;
+  q_stage.load(q_base, tok_stride, first_tile * kBN, T - 1, tid);
+  do_stage.load(do_base, o_stride, first_tile * kBN, T - 1, tid);
+  q_stage.store(smem, tid);
+  do_stage.store(smem + kTileBytes, tid);
+  __syncthreads();
+
+  for (int j = first_tile; j < n_tiles; ++j) {
+    const int buf = (j - first_tile) & 1;
+    const char* q_tile = smem + buf * 2 * kTileBytes;
+    const char* do_tile = q_tile + kTileBytes;
+    const bool has_next = j + 1 < n_tiles;
+    if (has_next) {
+      q_stage.load(q_base, tok_stride, (j + 1) * kBN, T - 1, tid);
+      do_stage.load(do_base, o_stride, (j + 1) * kBN, T - 1, tid);
+    }
+
+    if (wave_active) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {      // two 32-query sub-tiles
+        const int qs = j * kBN + sub * 32;     // first query of the sub-tile
+        if (qs + 31 < key0 || qs >= T) continue;  // wave-uniform: entirely above the diagonal / past the end
+        // Row constants of the 16 accumulator rows this lane holds (queries qs + acc_row(i, h)).
+        f32x16 s_acc, dp_acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int q = qs + 8 * g + 4 * h + e;
+            q = q < T ? q : T - 1;
+            s_acc[4 * g + e] = -lse_row[q] * inv_scale;  // chain ends as S - LSE/scale; exp2(c * acc) = P
+            dp_acc[4 * g + e] = -delta_row[q];
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+          const bf16x8 qa = lds_read_b128(q_tile, tile_off<D>(sub * 32 + r, 2 * ks + h));
+          s_acc = mfma32(qa, kf[ks], s_acc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+          const bf16x8 da = lds_read_b128(do_tile, tile_off<D>(sub * 32 + r, 2 * ks + h));
+          dp_acc = mfma32(da, vf[ks], dp_acc);
+        }
+        const bool diag = qs < key0 + 31;          // wave-uniform: some (q, key) pairs are masked
+        const bool tail = qs + 31 >= T;            // wave-uniform: padding queries in this sub-tile
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = qs + acc_row(i, h);
+          float p = __builtin_amdgcn_exp2f(s_acc[i] * c);
+          if ((diag && q < key) || (tail && q >= T)) p = 0.f;
+          s_acc[i] = p;
+          dp_acc[i] = p * dp_acc[i];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int o = 8 * s;
+          const bf16x8 pf = pack_acc8(s_acc[o], s_acc[o + 1], s_acc[o + 2], s_acc[o + 3], s_acc[o + 4],
+                                      s_acc[o + 5], s_acc[o + 6], s_acc[o + 7]);
+          const bf16x8 dsf = pack_acc8(dp_acc[o], dp_acc[o + 1], dp_acc[o + 2], dp_acc[o + 3], dp_acc[o + 4],
+                                       dp_acc[o + 5], dp_acc[o + 6], dp_acc[o + 7]);
+#pragma unroll
+          for (int db = 0; db < kDBlocks; ++db) {
+            const bf16x8 dot = tr_fragment<D>(do_tile, 2 * sub + s, db, lane);
+            dv_acc[db] = mfma32(dot, pf, dv_acc[db]);
+            const bf16x8 qt = tr_fragment<D>(q_tile, 2 * sub + s, db, lane);
+            dk_acc[db] = mfma32(qt, dsf, dk_acc[db]);
+          }
+        }
+      }
+    }
+
+    if (has_next) {
+      char* nq = smem + (buf ^ 1) * 2 * kTileBytes;
+      q_stage.store(nq, tid);
+      do_stage.store(nq + kTileBytes, tid);
+    }
+    __syncthreads();
+  }
+
+  if (key < T) {
+    bf16_raw* dk_row = dqkv + (int64_t(b) * T + key) * tok_stride + int64_t(H) * D + int64_t(head) * D;
+    bf16_raw* dv_row = dk_row + int64_t(H) * D;
+#pragma unroll
+    for (int db = 0; db < kDBlocks; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 wk = {pack_bf16x2(dk_acc[db][4 * g] * scale, dk_acc[db][4 * g + 1] * scale),
+                    pack_bf16x2(dk_acc[db][4 * g + 2] * scale, dk_acc[db][4 * g + 3] * scale)};
+        u32x2 wv = {pack_bf16x2(dv_acc[db][4 * g], dv_acc[db][4 * g + 1]),
+                    pack_bf16x2(dv_acc[db][4 * g + 2], dv_acc[db][4 * g + 3])};
+        *reinterpret_cast<u32x2*>(dk_row + db * 32 + 8 * g + 4 * h) = wk;
+        *reinterpret_cast<u32x2*>(dv_row + db * 32 + 8 * g + 4 * h) = wv;
+      }
+  }
+}
+
+}  // namespace
+
+void attention_backward(const void* qkv, const void* out, const void* dout, const float* lse,
+                        float* delta, void* dqkv, int B, int T, int H, int D, float softmax_scale,
+                        hipStream_t stream) {
+  const int n_bt = (T + kBM - 1) / kBM;
+  dim3 grid((unsigned)(n_bt * B * H)), block(kThreads);
+  if (D == 64) {
+    constexpr size_t lds = 2 * 2 * kBN * 64 * 2;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, lds, stream, (const bf16_raw*)qkv,
+                       (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H,
+                       softmax_scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, lds, stream, (const bf16_raw*)qkv,
+                       (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale);
+  } else {
+    constexpr size_t lds = 2 * 2 * kBN * 128 * 2;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, block, lds, stream, (const bf16_raw*)qkv,
+                       (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H,
+                       softmax_scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, block, lds, stream, (const bf16_raw*)qkv,
+                       (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale);
+  }
+}
+
+}  // namespace pda

@@ -26,7 +26,7 @@ _PAD = 128
 
 
 def cross_entropy_reference(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = -100):
-    return F.cross_entropy(logits.float().view(-1, logits.shape[-1]), targets.view(-1),
+    return F.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), targets.reshape(-1),
                            ignore_index=ignore_index)
 
 

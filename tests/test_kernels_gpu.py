@@ -180,8 +180,8 @@ def test_fused_adamw_matches_torch(dtype):
     for p, r in zip(params, ref_params):
         master = opt.state[p].get("master", p.data)
         assert rel_err(master, r) < 1e-6
-        assert rel_err(opt.state[p]["exp_avg"], ref.state[r]["exp_avg"]) < 1e-5
-        assert rel_err(opt.state[p]["exp_avg_sq"], ref.state[r]["exp_avg_sq"]) < 1e-5
+        assert rel_err(opt.state[p]["exp_avg"], ref.state[r]["exp_avg"]) < 5e-5
+        assert rel_err(opt.state[p]["exp_avg_sq"], ref.state[r]["exp_avg_sq"]) < 5e-5
         if dtype == torch.bfloat16:
             assert torch.equal(p.data, master.to(torch.bfloat16))
 
@@ -224,3 +224,38 @@ def test_attention_forward_structured():
     ref = ops.attention_reference(qkv.float(), H, scale=1.0)
     assert (out.float() - ref).abs().max().item() <= 8.0  # bf16 resolution at magnitude ~1000-2000
     assert rel_err(out, ref) < 5e-3
+
+
+@pytest.mark.parametrize("B,T,H,D", [(2, 1024, 4, 64), (1, 333, 3, 64), (2, 256, 2, 128), (1, 640, 2, 128),
+                                     (1, 64, 1, 64), (2, 1000, 5, 64)])
+def test_attention_backward(B, T, H, D):
+    _ext_loaded()
+    torch.manual_seed(8)
+    qkv = torch.randn(B, T, 3 * H * D, device=DEV, dtype=torch.bfloat16)
+    dout = torch.randn(B, T, H * D, device=DEV, dtype=torch.bfloat16)
+    a = qkv.clone().requires_grad_(True)
+    out = ops.causal_attention(a, H)
+    out.backward(dout)
+    r = qkv.float().requires_grad_(True)
+    ref = ops.attention_reference(r, H)
+    ref.backward(dout.float())
+    assert rel_err(out, ref) < 1e-2
+    d = 3 * H * D
+    g, gr = a.grad.view(B, T, 3, H * D), r.grad.view(B, T, 3, H * D)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        e = rel_err(g[:, :, i], gr[:, :, i])
+        assert e < 2e-2, (name, e)
+
+
+def test_attention_backward_deterministic():
+    _ext_loaded()
+    torch.manual_seed(9)
+    B, T, H, D = 2, 512, 4, 64
+    qkv = torch.randn(B, T, 3 * H * D, device=DEV, dtype=torch.bfloat16)
+    dout = torch.randn(B, T, H * D, device=DEV, dtype=torch.bfloat16)
+    grads = []
+    for _ in range(2):
+        a = qkv.clone().requires_grad_(True)
+        ops.causal_attention(a, H).backward(dout)
+        grads.append(a.grad.clone())
+    assert torch.equal(grads[0], grads[1])
