@@ -15,5 +15,8 @@ PYBIND11_MODULE(_C, m) {
   m.doc() = "MI355X-native kernels and runtime for pytorch_distributed_amd";
   m.attr("arch") = "gfx950";
   bind_ops(m);
-  // bind_reducer(m); bind_fsdp(m); bind_loader(m); bind_tracer(m);  (added as they land)
+  bind_reducer(m);
+  bind_fsdp(m);
+  bind_loader(m);
+  bind_tracer(m);
 }

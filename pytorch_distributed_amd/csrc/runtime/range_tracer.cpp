@@ -1,0 +1,202 @@
+// Range tracer: named host + GPU time ranges -> Chrome-trace JSON, mirrored to roctx.
+//
+// Every push/pop pair records the host wall-clock interval and, when a GPU is in use, a pair
+// of HIP events on the calling thread's current stream, so the exported trace shows both
+// where the host spent its time launching a phase (forward, backward, optimizer, all-gather
+// wait, ...) and when the GPU actually executed it. The same ranges are forwarded to
+// roctxRangePush / roctxRangePop when libroctx64 is loadable, so a rocprofv3 marker trace
+// of the same run carries identical annotations next to the kernel rows.
+//
+// This is the light-weight, always-available half of the profiling story (the reference
+// wraps training in torch.profiler: assignments/assignment1/train_baseline.py:79-87);
+// kernel-level traces come from rocprofv3 / the Kineto backend of utils.profiler.
+#include <c10/hip/HIPStream.h>
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/extension.h>
+
+#include <chrono>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+double now_us() {
+  return std::chrono::duration<double, std::micro>(Clock::now().time_since_epoch()).count();
+}
+
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    void* lib = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
+    if (!lib) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+  }
+};
+
+Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+
+struct Range {
+  std::string name, cat;
+  double host_begin = 0, host_end = 0;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  int depth = 0;
+};
+
+std::string json_escape(const std::string& s) {
+  std::string o;
+  for (char c : s) {
+    if (c == '"' || c == '\\') o += '\\';
+    if (c == '\n') { o += "\\n"; continue; }
+    o += c;
+  }
+  return o;
+}
+
+class RangeTracer {
+ public:
+  explicit RangeTracer(bool use_gpu) : use_gpu_(use_gpu) {
+    if (use_gpu_) {
+      TORCH_CHECK(hipEventCreate(&base_event_) == hipSuccess, "hipEventCreate failed");
+      hipStream_t s = c10::hip::getCurrentHIPStream().stream();
+      TORCH_CHECK(hipEventRecord(base_event_, s) == hipSuccess, "hipEventRecord failed");
+      hipEventSynchronize(base_event_);
+    }
+    base_host_ = now_us();
+  }
+
+  ~RangeTracer() {
+    for (auto& r : done_) destroy(r);
+    for (auto& r : open_) destroy(r);
+    if (base_event_) hipEventDestroy(base_event_);
+  }
+
+  void set_enabled(bool e) { enabled_ = e; }
+  bool enabled() const { return enabled_; }
+
+  void push(const std::string& name, const std::string& cat) {
+    if (roctx().push) roctx().push(name.c_str());
+    std::lock_guard<std::mutex> lk(mu_);
+    Range r;
+    r.name = name;
+    r.cat = cat;
+    r.depth = (int)open_.size();
+    r.host_begin = now_us();
+    if (enabled_ && use_gpu_) {
+      hipEventCreate(&r.ev_begin);
+      hipEventRecord(r.ev_begin, c10::hip::getCurrentHIPStream().stream());
+    }
+    open_.push_back(std::move(r));
+  }
+
+  void pop() {
+    if (roctx().pop) roctx().pop();
+    std::lock_guard<std::mutex> lk(mu_);
+    TORCH_CHECK(!open_.empty(), "RangeTracer.pop without a matching push");
+    Range r = std::move(open_.back());
+    open_.pop_back();
+    r.host_end = now_us();
+    if (r.ev_begin) {
+      hipEventCreate(&r.ev_end);
+      hipEventRecord(r.ev_end, c10::hip::getCurrentHIPStream().stream());
+    }
+    if (enabled_) done_.push_back(std::move(r));
+    else destroy(r);
+  }
+
+  void instant(const std::string& name) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (enabled_) instants_.emplace_back(name, now_us());
+  }
+
+  int64_t num_ranges() const { return (int64_t)done_.size(); }
+
+  // Chrome trace: pid = rank; tid 0 = host ranges, tid 1 = the same ranges on the GPU clock.
+  std::string to_json(int64_t rank) {
+    std::lock_guard<std::mutex> lk(mu_);
+    std::ostringstream o;
+    o.setf(std::ios::fixed);
+    o.precision(3);
+    o << "{\"schemaVersion\":1,\"distributedInfo\":{\"rank\":" << rank << "},\"traceEvents\":[\n";
+    o << "{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":0,\"name\":\"thread_name\",\"args\":{\"name\":\"host ranges\"}},\n";
+    o << "{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":1,\"name\":\"thread_name\",\"args\":{\"name\":\"gpu ranges (stream order)\"}}";
+    for (auto& r : done_) {
+      o << ",\n{\"ph\":\"X\",\"cat\":\"" << json_escape(r.cat) << "\",\"name\":\"" << json_escape(r.name)
+        << "\",\"pid\":" << rank << ",\"tid\":0,\"ts\":" << (r.host_begin - base_host_)
+        << ",\"dur\":" << (r.host_end - r.host_begin) << "}";
+      if (r.ev_begin && r.ev_end) {
+        hipEventSynchronize(r.ev_end);
+        float b_ms = 0.f, d_ms = 0.f;
+        if (hipEventElapsedTime(&b_ms, base_event_, r.ev_begin) == hipSuccess &&
+            hipEventElapsedTime(&d_ms, r.ev_begin, r.ev_end) == hipSuccess) {
+          o << ",\n{\"ph\":\"X\",\"cat\":\"gpu_" << json_escape(r.cat) << "\",\"name\":\"" << json_escape(r.name)
+            << "\",\"pid\":" << rank << ",\"tid\":1,\"ts\":" << (double)b_ms * 1e3 << ",\"dur\":" << (double)d_ms * 1e3
+            << "}";
+        }
+      }
+    }
+    for (auto& [name, ts] : instants_)
+      o << ",\n{\"ph\":\"i\",\"s\":\"p\",\"name\":\"" << json_escape(name) << "\",\"pid\":" << rank
+        << ",\"tid\":0,\"ts\":" << (ts - base_host_) << "}";
+    o << "\n]}\n";
+    return o.str();
+  }
+
+  void save(const std::string& path, int64_t rank) {
+    std::string s = to_json(rank);
+    std::ofstream f(path);
+    TORCH_CHECK(f.good(), "cannot write trace to ", path);
+    f << s;
+  }
+
+  void clear() {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto& r : done_) destroy(r);
+    done_.clear();
+    instants_.clear();
+  }
+
+ private:
+  static void destroy(Range& r) {
+    if (r.ev_begin) hipEventDestroy(r.ev_begin);
+    if (r.ev_end) hipEventDestroy(r.ev_end);
+    r.ev_begin = r.ev_end = nullptr;
+  }
+
+  bool use_gpu_;
+  bool enabled_ = true;
+  hipEvent_t base_event_ = nullptr;
+  double base_host_ = 0;
+  std::vector<Range> open_, done_;
+  std::vector<std::pair<std::string, double>> instants_;
+  std::mutex mu_;
+};
+
+}  // namespace
+
+void bind_tracer(py::module_& m) {
+  py::class_<RangeTracer>(m, "RangeTracer")
+      .def(py::init<bool>(), py::arg("use_gpu"))
+      .def("push", &RangeTracer::push, py::arg("name"), py::arg("cat") = "range")
+      .def("pop", &RangeTracer::pop)
+      .def("instant", &RangeTracer::instant)
+      .def("set_enabled", &RangeTracer::set_enabled)
+      .def("enabled", &RangeTracer::enabled)
+      .def("to_json", &RangeTracer::to_json, py::arg("rank") = 0)
+      .def("save", &RangeTracer::save, py::arg("path"), py::arg("rank") = 0)
+      .def("clear", &RangeTracer::clear)
+      .def_property_readonly("num_ranges", &RangeTracer::num_ranges);
+}

@@ -1,0 +1,285 @@
+// Gradient-bucket reducer: the engine underneath pytorch_distributed_amd.parallel.DDP.
+//
+// What it owns
+//   * Flat gradient buckets. Parameters are assigned to buckets in REVERSE registration
+//     order (the order their gradients become ready in backward); every parameter's
+//     .grad is a view into its bucket, so reduction needs no gather / scatter copies and
+//     the optimizer sees the reduced values in place.
+//   * Post-accumulate hooks on every parameter's AccumulateGrad node (C++, no GIL). When
+//     the last gradient of a bucket has been accumulated, the bucket is all-reduced
+//     asynchronously. Buckets launch strictly in index order on every rank.
+//   * One end-of-backward callback that launches whatever is still pending (buckets
+//     whose parameters received no gradient this pass) and makes the compute stream wait
+//     for all outstanding collectives (an event wait, never a host synchronisation on
+//     the GPU backend).
+//   * no_sync: hooks keep accumulating into the bucket views, nothing is launched.
+//
+// Collectives go through c10d::ProcessGroup, i.e. RCCL on GPUs ("nccl" backend, which
+// runs each collective on its own HIP stream and fences it against the caller's stream
+// with events) and gloo on CPUs, so the same reducer is exercised by the CPU tests.
+//
+// Bucket size: a ring all-reduce over xGMI is bound by one of the 7 point-to-point links
+// per GPU and every bucket is cut into world-size chunks, so buckets default to 64 MiB
+// (8 MiB chunks at 8 GPUs) rather than the 25 MiB of NVSwitch-era defaults; the first
+// bucket is small so communication starts early in backward.
+//
+// Reference behaviour being replaced: torch DDP as constructed at
+// assignments/assignment1/train_ddp.py:46-49 and its no_sync() use at
+// assignments/assignment1/train/distributed_trainer.py:115-127.
+#include <torch/csrc/autograd/engine.h>
+#include <torch/csrc/autograd/utils/lambda_post_hook.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+#include <torch/extension.h>
+
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+constexpr int64_t kAlignElems = 64;  // every parameter starts on a 128-byte (bf16) / 256-byte (fp32) boundary
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Bucket {
+  at::Tensor flat;               // the gradient storage
+  std::vector<size_t> params;    // indices into GradReducer::params_
+  std::vector<int64_t> offsets;  // element offset of each parameter inside `flat`
+  size_t pending = 0;            // parameters whose gradient has not arrived this pass
+  bool launched = false;
+  c10::intrusive_ptr<c10d::Work> work;
+};
+
+class GradReducer {
+ public:
+  GradReducer(std::vector<at::Tensor> params, c10::intrusive_ptr<c10d::ProcessGroup> pg,
+              int64_t bucket_cap_bytes, int64_t first_bucket_bytes, bool force_collectives)
+      : params_(std::move(params)), pg_(std::move(pg)), force_collectives_(force_collectives) {
+    TORCH_CHECK(!params_.empty(), "GradReducer: no parameters");
+    TORCH_CHECK(bucket_cap_bytes > 0 && first_bucket_bytes > 0, "GradReducer: bucket sizes must be positive");
+    world_ = pg_ ? pg_->getSize() : 1;
+    backend_ = pg_ ? pg_->getBackendName() : "none";
+    build_buckets(bucket_cap_bytes, first_bucket_bytes);
+    install_hooks();
+  }
+
+  ~GradReducer() { remove_hooks(); }
+
+  void set_sync(bool sync) { require_sync_ = sync; }
+  bool sync_enabled() const { return require_sync_; }
+
+  // Detaches from the parameters (gradients stay valid views; no more hooks fire).
+  void remove_hooks() {
+    for (size_t i = 0; i < accumulators_.size(); ++i) {
+      if (accumulators_[i]) accumulators_[i]->del_post_hook(hook_keys_[i]);
+    }
+    accumulators_.clear();
+    hook_keys_.clear();
+  }
+
+  void zero_grad() {
+    for (auto& b : buckets_) b.flat.zero_();
+  }
+
+  std::vector<at::Tensor> bucket_tensors() const {
+    std::vector<at::Tensor> out;
+    for (auto& b : buckets_) out.push_back(b.flat);
+    return out;
+  }
+
+  std::vector<std::vector<int64_t>> bucket_param_indices() const {
+    std::vector<std::vector<int64_t>> out;
+    for (auto& b : buckets_) out.emplace_back(b.params.begin(), b.params.end());
+    return out;
+  }
+
+  int64_t num_collectives() const { return num_collectives_; }
+  int64_t num_buckets() const { return (int64_t)buckets_.size(); }
+  int64_t num_rebound_grads() const { return num_rebound_; }
+
+ private:
+  // ---- construction -------------------------------------------------------------
+  void build_buckets(int64_t cap_bytes, int64_t first_bytes) {
+    // Reverse registration order; a bucket holds one (dtype, device) only.
+    std::vector<size_t> order(params_.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = params_.size() - 1 - i;
+    param_bucket_.assign(params_.size(), {0, 0});
+    std::vector<size_t> cur;
+    int64_t cur_elems = 0;
+    bool first = true;
+    auto flush = [&]() {
+      if (cur.empty()) return;
+      const at::Tensor& p0 = params_[cur[0]];
+      Bucket b;
+      b.flat = at::zeros({cur_elems}, p0.options().requires_grad(false));
+      int64_t off = 0;
+      for (size_t idx : cur) {
+        b.params.push_back(idx);
+        b.offsets.push_back(off);
+        param_bucket_[idx] = {buckets_.size(), b.offsets.size() - 1};
+        off += align_up(params_[idx].numel(), kAlignElems);
+      }
+      buckets_.push_back(std::move(b));
+      cur.clear();
+      cur_elems = 0;
+      first = false;
+    };
+    for (size_t idx : order) {
+      const at::Tensor& p = params_[idx];
+      TORCH_CHECK(p.requires_grad() && p.is_leaf(), "GradReducer: parameter ", idx, " is not a trainable leaf");
+      if (!cur.empty()) {
+        const at::Tensor& p0 = params_[cur[0]];
+        if (p0.scalar_type() != p.scalar_type() || p0.device() != p.device()) flush();
+      }
+      const int64_t limit = (first ? first_bytes : cap_bytes) / p.element_size();
+      const int64_t need = align_up(p.numel(), kAlignElems);
+      if (!cur.empty() && cur_elems + need > limit) flush();
+      cur.push_back(idx);
+      cur_elems += need;
+    }
+    flush();
+    // Point every .grad at its bucket slice (preserving an existing gradient's value).
+    for (size_t i = 0; i < params_.size(); ++i) bind_grad_view(i, /*copy_existing=*/true);
+  }
+
+  at::Tensor grad_view(size_t idx) const {
+    const auto [b, slot] = param_bucket_[idx];
+    const at::Tensor& p = params_[idx];
+    return buckets_[b].flat.narrow(0, buckets_[b].offsets[slot], p.numel()).view(p.sizes());
+  }
+
+  void bind_grad_view(size_t idx, bool copy_existing) {
+    at::Tensor& p = params_[idx];
+    at::Tensor view = grad_view(idx);
+    at::Tensor& g = p.mutable_grad();
+    if (copy_existing && g.defined() && g.data_ptr() != view.data_ptr()) {
+      at::NoGradGuard ng;
+      view.copy_(g);
+    }
+    g = view;
+  }
+
+  void install_hooks() {
+    for (size_t i = 0; i < params_.size(); ++i) {
+      auto acc = torch::autograd::impl::grad_accumulator(params_[i]);
+      auto key = acc->add_post_hook(std::make_unique<torch::autograd::utils::LambdaPostHook>(
+          [this, i](const torch::autograd::variable_list& outputs,
+                    const torch::autograd::variable_list& /*inputs*/) {
+            this->on_grad_ready(i);
+            return outputs;
+          }));
+      accumulators_.push_back(std::move(acc));
+      hook_keys_.push_back(key);
+    }
+  }
+
+  // ---- backward pass ------------------------------------------------------------
+  void begin_pass() {
+    in_pass_ = true;
+    next_bucket_ = 0;
+    for (auto& b : buckets_) {
+      b.pending = b.params.size();
+      b.launched = false;
+      b.work.reset();
+    }
+    ready_.assign(params_.size(), false);
+    torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finish_pass(); });
+  }
+
+  void on_grad_ready(size_t idx) {
+    std::lock_guard<std::mutex> lock(mu_);
+    // If something replaced .grad (e.g. zero_grad(set_to_none=True) followed by a fresh
+    // gradient tensor), fold it back into the bucket so the view invariant holds again.
+    {
+      const at::Tensor& g = params_[idx].grad();
+      at::Tensor view = grad_view(idx);
+      if (g.defined() && g.data_ptr() != view.data_ptr()) {
+        at::NoGradGuard ng;
+        view.copy_(g);  // the bucket slice was not written this pass: overwrite, do not add
+        params_[idx].mutable_grad() = view;
+        ++num_rebound_;
+      }
+    }
+    if (!require_sync_) return;
+    if (!in_pass_) begin_pass();
+    if (ready_[idx]) return;  // a second accumulation in the same pass: already counted
+    ready_[idx] = true;
+    Bucket& b = buckets_[param_bucket_[idx].first];
+    if (b.pending > 0) --b.pending;
+    launch_ready_buckets(/*flush=*/false);
+  }
+
+  void launch_ready_buckets(bool flush) {
+    while (next_bucket_ < buckets_.size()) {
+      Bucket& b = buckets_[next_bucket_];
+      if (!flush && b.pending > 0) break;  // keep the launch order identical on all ranks
+      launch(b);
+      ++next_bucket_;
+    }
+  }
+
+  void launch(Bucket& b) {
+    b.launched = true;
+    if (world_ == 1 && !force_collectives_) return;
+    std::vector<at::Tensor> tensors{b.flat};
+    c10d::AllreduceOptions opts;
+    const bool native_avg = backend_ == "nccl";
+    opts.reduceOp = native_avg ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
+    b.work = pg_->allreduce(tensors, opts);
+    ++num_collectives_;
+  }
+
+  void finish_pass() {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (!in_pass_) return;
+    launch_ready_buckets(/*flush=*/true);
+    const bool native_avg = backend_ == "nccl";
+    for (auto& b : buckets_) {
+      if (!b.work) continue;
+      b.work->wait();  // GPU: current stream waits on the collective's event; CPU: blocks
+      if (!native_avg && world_ > 1) {
+        at::NoGradGuard ng;
+        b.flat.div_((double)world_);
+      }
+      b.work.reset();
+    }
+    in_pass_ = false;
+  }
+
+  std::vector<at::Tensor> params_;
+  c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+  int world_ = 1;
+  std::string backend_;
+  bool force_collectives_ = false;
+  bool require_sync_ = true;
+  bool in_pass_ = false;
+  size_t next_bucket_ = 0;
+  std::vector<Bucket> buckets_;
+  std::vector<std::pair<size_t, size_t>> param_bucket_;  // param -> (bucket, slot)
+  std::vector<bool> ready_;
+  std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
+  std::vector<uintptr_t> hook_keys_;
+  std::mutex mu_;
+  int64_t num_collectives_ = 0;
+  int64_t num_rebound_ = 0;
+};
+
+}  // namespace
+
+void bind_reducer(py::module_& m) {
+  py::class_<GradReducer, std::shared_ptr<GradReducer>>(m, "GradReducer")
+      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int64_t, int64_t, bool>(),
+           py::arg("params"), py::arg("process_group"), py::arg("bucket_cap_bytes"),
+           py::arg("first_bucket_bytes"), py::arg("force_collectives") = false)
+      .def("set_sync", &GradReducer::set_sync)
+      .def("sync_enabled", &GradReducer::sync_enabled)
+      .def("remove_hooks", &GradReducer::remove_hooks)
+      .def("zero_grad", &GradReducer::zero_grad)
+      .def("bucket_tensors", &GradReducer::bucket_tensors)
+      .def("bucket_param_indices", &GradReducer::bucket_param_indices)
+      .def_property_readonly("num_collectives", &GradReducer::num_collectives)
+      .def_property_readonly("num_buckets", &GradReducer::num_buckets)
+      .def_property_readonly("num_rebound_grads", &GradReducer::num_rebound_grads);
+}

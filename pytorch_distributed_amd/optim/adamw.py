@@ -65,6 +65,7 @@ class FusedAdamW(torch.optim.Optimizer):
             beta1, beta2 = group["betas"]
             gpu: Dict[tuple, List] = {}
             step_val = None
+            drop_after: List[torch.Tensor] = []
             for p in group["params"]:
                 grad = getattr(p, "_pda_main_grad", None)
                 if grad is None:
@@ -76,6 +77,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 st = self._init_state(p)
                 st["step"] += 1
                 step_val = int(st["step"].item())
+                # Shard gradients of the sharded-data-parallel runtime are re-created by every
+                # reduction: drop them after the update instead of zeroing them.
+                drop = zero_grad and getattr(p, "_pda_free_grad_after_step", False)
+                if drop:
+                    drop_after.append(p)
                 if p.is_cuda and not _ext.force_reference():
                     if p.dtype == torch.float32:
                         master, lowp = p.data, getattr(p, "_pda_lowp", None)
@@ -83,18 +89,20 @@ class FusedAdamW(torch.optim.Optimizer):
                         master, lowp = st["master"], p.data
                     if not (master.is_contiguous() and grad.is_contiguous()):
                         raise RuntimeError("FusedAdamW needs contiguous parameters and gradients")
-                    key = (grad.dtype, step_val, p.device)
+                    key = (grad.dtype, step_val, p.device, zero_grad and not drop)
                     gpu.setdefault(key, [[], [], [], [], []])
                     for lst, item in zip(gpu[key], (master.view(-1), None if lowp is None else lowp.view(-1),
                                                     grad.view(-1), st["exp_avg"].view(-1),
                                                     st["exp_avg_sq"].view(-1))):
                         lst.append(item)
                 else:
-                    self._reference_update(p, grad, st, group, step_val, grad_scale, zero_grad)
-            for (gdtype, step_i, _dev), (masters, lowps, grads, m, v) in gpu.items():
+                    self._reference_update(p, grad, st, group, step_val, grad_scale, zero_grad and not drop)
+            for (gdtype, step_i, _dev, zero_here), (masters, lowps, grads, m, v) in gpu.items():
                 _ext.require().adamw_step(masters, lowps, grads, m, v, group["lr"], beta1, beta2,
                                           group["eps"], group["weight_decay"], step_i, grad_scale,
-                                          zero_grad)
+                                          zero_here)
+            for p in drop_after:
+                p.grad = None
         self._grads_cleared_by_step = zero_grad
         return loss
 

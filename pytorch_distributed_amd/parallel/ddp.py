@@ -1,0 +1,97 @@
+"""DistributedDataParallel on the native gradient-bucket reducer.
+
+``DDP(model, device_ids=[local_rank])`` keeps the constructor shape the reference uses
+(assignments/assignment1/train_ddp.py:46-49) and the wrapper surface its trainer relies on:
+``no_sync()``, ``parameters()``, ``state_dict()`` / ``load_state_dict()``, ``train()`` /
+``eval()``, call-through ``forward`` — plus ``.device`` and unprefixed ``state_dict`` keys so
+checkpoints load into the bare model and vice versa.
+
+All per-gradient work happens in C++ (``csrc/runtime/reducer.cpp``): gradients are views of
+flat buckets, buckets are all-reduced over RCCL from autograd hooks while backward is
+still running, and the optimizer is fenced behind the collectives by an end-of-backward
+stream wait. Not reproduced from torch DDP because the model gives it no purpose: the
+per-forward buffer broadcast (this GPT-2 has no buffers — the reference's ``causal_mask``
+buffers cost 36 MiB of broadcast per forward) and the unused-parameter graph search
+(buckets whose parameters got no gradient are simply flushed at the end of backward).
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import _ext
+from . import comm
+
+DEFAULT_BUCKET_CAP_MB = 64.0
+DEFAULT_FIRST_BUCKET_MB = 4.0
+
+
+class DDP(nn.Module):
+    def __init__(self, module: nn.Module, device_ids=None, process_group=None,
+                 bucket_cap_mb: float = DEFAULT_BUCKET_CAP_MB, first_bucket_mb: float = DEFAULT_FIRST_BUCKET_MB,
+                 broadcast_parameters: bool = True, force_collectives: bool = False):
+        super().__init__()
+        if not dist.is_initialized():
+            raise RuntimeError("DDP needs an initialised process group (parallel.init_distributed())")
+        self.module = module
+        self.process_group = process_group if process_group is not None else comm.default_group()
+        self.world_size = dist.get_world_size(self.process_group)
+        self.rank = dist.get_rank(self.process_group)
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("DDP: the module has no trainable parameters")
+        if device_ids is not None and len(device_ids) == 1 and params[0].is_cuda:
+            want = torch.device("cuda", device_ids[0]) if isinstance(device_ids[0], int) else torch.device(device_ids[0])
+            if params[0].device != want:
+                raise ValueError(f"DDP: module lives on {params[0].device}, device_ids says {want}")
+        self._params = params
+
+        # Same shapes everywhere, then rank 0's values everywhere (parameters and buffers).
+        comm.assert_same_across_ranks([p.numel() for p in params], "parameter sizes", self.process_group)
+        if broadcast_parameters and self.world_size > 1:
+            tensors = [p.data for p in params] + [b.data for b in module.buffers()]
+            dist._broadcast_coalesced(self.process_group, tensors, 256 * 1024 * 1024, 0)
+
+        ext = _ext.require()
+        self.reducer = ext.GradReducer(params, self.process_group, int(bucket_cap_mb * 2**20),
+                                       int(first_bucket_mb * 2**20), force_collectives)
+        for p in params:
+            p._pda_grad_is_view = True  # optimizers must zero these in place, never drop them
+
+    # -- module surface ----------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    @property
+    def device(self) -> torch.device:
+        return self._params[0].device
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside accumulate into the bucket views without communicating."""
+        previous = self.reducer.sync_enabled()
+        self.reducer.set_sync(False)
+        try:
+            yield
+        finally:
+            self.reducer.set_sync(previous)
+
+    def state_dict(self, *args, **kwargs):
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        state_dict = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        return self.module.load_state_dict(state_dict, *args, **kwargs)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.reducer.zero_grad()
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("module"), name)
