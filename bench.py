@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=None)
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--wrap-single", action="store_true",
+                    help="with --gpus 1: still wrap in DDP/FSDP and force the RCCL collectives (rehearsal)")
     return ap.parse_args()
 
 
@@ -67,7 +69,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.wrap_single
     if distributed:
         from pytorch_distributed_amd.parallel import init_distributed
         init_distributed(backend="nccl")
@@ -83,12 +85,12 @@ def main():
         if args.mode == "ddp":
             from pytorch_distributed_amd.parallel import DDP
             kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
-            model = DDP(model, device_ids=[local_rank], **kw)
+            model = DDP(model, device_ids=[local_rank], force_collectives=args.wrap_single, **kw)
             parallelism = f"ddp{world}"
         else:
             from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
             kw = {} if args.fsdp_unit_blocks is None else {"unit_blocks": args.fsdp_unit_blocks}
-            model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], **kw)
+            model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], force_collectives=args.wrap_single, **kw)
             parallelism = f"fsdp_{args.strategy.lower()}{world}"
     optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1)
 

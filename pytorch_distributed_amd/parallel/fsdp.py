@@ -270,6 +270,17 @@ class FSDP(nn.Module):
                 result = self.module.load_state_dict(fixed, strict=strict, **kwargs)
         return result
 
+    def full_optim_state_dict(self, optimizer, cpu_offload: bool = True):
+        """Optimizer state in torch.optim.AdamW layout over the bare model's parameters (collective)."""
+        from .checkpoint import full_optim_state_dict
+
+        return full_optim_state_dict(self, optimizer, cpu_offload)
+
+    def load_full_optim_state_dict(self, optimizer, state) -> None:
+        from .checkpoint import load_full_optim_state_dict
+
+        load_full_optim_state_dict(self, optimizer, state)
+
     def __getattr__(self, name):
         try:
             return super().__getattr__(name)

@@ -1,0 +1,106 @@
+"""Shared command-line plumbing of the train scripts.
+
+The reference hard-codes every hyper-parameter inside ``main()``
+(assignments/assignment1/train_baseline.py:24-31, train_ddp.py:59-64, train_fsdp.py:98-103).
+The flags below default to exactly those literals (GPT-2 Large, global batch 32, micro
+batch 8, sequence length 1024, 20 steps, lr 3e-4, weight decay 0.1, cosine to 0.1 x lr, 10
+training shards, profiler schedule 2/2/6/1), so running a script without arguments is the
+reference's run; everything else is opt-in.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+from typing import List, Optional
+
+import torch
+
+from ..data import (DistributedKJJ0DataLoader, KJJ0DataLoader, SyntheticTokenLoader,
+                    download_fineweb10B_files, make_synthetic_fineweb_files)
+from ..models import MyGPT2LMHeadModel, get_config
+from ..optim import CosineAnnealingLR, FusedAdamW
+
+
+def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
+    ap.add_argument("--model", default="gpt2-large", help="gpt2 | gpt2-medium | gpt2-large | gpt2-xl | llama-7b ...")
+    ap.add_argument("--global-batch-size", type=int, default=32)
+    ap.add_argument("--micro-batch-size", type=int, default=8)
+    ap.add_argument("--sequence-length", type=int, default=1024)
+    ap.add_argument("--max-steps", type=int, default=20)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--weight-decay", type=float, default=0.1)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None, help="default: bf16 on GPU, fp32 on CPU")
+    ap.add_argument("--dropout", type=float, default=None, help="override all dropout probabilities (config: 0.1)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--log-every", type=int, default=10)
+    ap.add_argument("--synthetic-data", action="store_true", help="random tokens generated on the device")
+    ap.add_argument("--data-dir", default=".cache/data/fineweb10B")
+    ap.add_argument("--num-train-files", type=int, default=10)
+    ap.add_argument("--make-synthetic-shards", action="store_true",
+                    help="write random .bin shards into --data-dir instead of downloading")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profiler-backend", choices=["auto", "kineto", "range"], default="auto")
+    ap.add_argument("--trace-dir", default=None)
+    ap.add_argument("--save-every", type=int, default=None)
+    ap.add_argument("--checkpoint-dir", default="checkpoints")
+    ap.add_argument("--resume", default=None, help="checkpoint path, or 'latest' to pick the newest in --checkpoint-dir")
+    ap.add_argument("--metrics-file", default=None)
+    ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="selective")
+    return ap
+
+
+def resolve_dtype(args, device) -> torch.dtype:
+    if args.dtype is None:
+        return torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32
+    return torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+
+def build_model(args, device, dtype):
+    cfg = get_config(args.model)
+    if hasattr(cfg, "attn_pdrop") and args.dropout is not None:
+        cfg.attn_pdrop = cfg.resid_pdrop = cfg.embd_pdrop = args.dropout
+    torch.manual_seed(args.seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(args.seed)
+    if hasattr(cfg, "intermediate_size"):
+        from ..models.llama import LlamaForCausalLM
+        model = LlamaForCausalLM(cfg)
+    else:
+        model = MyGPT2LMHeadModel(cfg, activation_checkpoint=args.activation_checkpoint)
+    return model.to(device=device, dtype=dtype), cfg
+
+
+def build_optimizer(args, params):
+    opt = FusedAdamW(params, lr=args.lr, weight_decay=args.weight_decay)
+    sched = CosineAnnealingLR(opt, T_max=args.max_steps, eta_min=args.lr * 0.1)
+    return opt, sched
+
+
+def train_files(args) -> List[str]:
+    if args.make_synthetic_shards:
+        files = make_synthetic_fineweb_files(args.data_dir, args.num_train_files)
+    else:
+        files = download_fineweb10B_files(args.data_dir, num_train_files=args.num_train_files)
+    return [str(f) for f in files if "train" in str(f)]
+
+
+def build_loader(args, cfg, device, distributed: bool, rank: int = 0):
+    if args.synthetic_data:
+        return SyntheticTokenLoader(args.micro_batch_size, args.sequence_length, cfg.vocab_size, device,
+                                    seed=1234 + rank)
+    files = train_files(args)
+    if distributed:
+        return DistributedKJJ0DataLoader(files, args.micro_batch_size, args.sequence_length, device)
+    return KJJ0DataLoader(files, args.micro_batch_size, args.sequence_length, device)
+
+
+def resolve_resume(args) -> Optional[str]:
+    if not args.resume:
+        return None
+    if args.resume != "latest":
+        return args.resume
+    cands = glob.glob(os.path.join(args.checkpoint_dir, "checkpoint_step_*.pt"))
+    if not cands:
+        return None
+    return max(cands, key=lambda p: int(p.rsplit("_", 1)[1].split(".")[0]))
