@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=None)
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
     ap.add_argument("--wrap-single", action="store_true",
                     help="with --gpus 1: still wrap in DDP/FSDP and force the RCCL collectives (rehearsal)")
     return ap.parse_args()
@@ -69,6 +70,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    tuned = False
+    if not args.no_tuned_gemms:
+        from pytorch_distributed_amd.tuning import enable_tuned_gemms
+        tuned = enable_tuned_gemms()
     distributed = world > 1 or args.wrap_single
     if distributed:
         from pytorch_distributed_amd.parallel import init_distributed
@@ -145,7 +150,7 @@ def main():
             "config": {"model": args.model, "global_batch": global_batch, "micro_batch": args.micro_batch,
                        "grad_accum": accum, "seq_len": args.seq_len, "parallelism": parallelism,
                        "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
-                       "flops_per_token": fpt},
+                       "flops_per_token": fpt, "tuned_gemm_table": tuned},
         }), flush=True)
     if distributed:
         dist.destroy_process_group()

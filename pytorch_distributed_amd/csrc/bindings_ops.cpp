@@ -319,9 +319,46 @@ at::Tensor attention_backward(const at::Tensor& qkv, const at::Tensor& out, cons
   return dqkv;
 }
 
+// ---------------------------------------------------------------- weight grad --
+bool wgrad_supported(int64_t M, int64_t I, int64_t J) { return pda::wgrad_supported((int)M, (int)I, (int)J); }
+
+// dW[I, J] = dy[M, I]^T . x[M, J] and (optionally) db[I] = column sums of dy, both bf16.
+std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, bool want_bias) {
+  TORCH_CHECK(dy.is_cuda() && x.is_cuda() && dy.dim() == 2 && x.dim() == 2, "wgrad: 2-D GPU tensors");
+  TORCH_CHECK(dy.scalar_type() == at::kBFloat16 && x.scalar_type() == at::kBFloat16, "wgrad: bf16 only");
+  TORCH_CHECK(dy.stride(1) == 1 && x.stride(1) == 1, "wgrad: rows must be contiguous");
+  const int64_t M = dy.size(0), I = dy.size(1), J = x.size(1);
+  TORCH_CHECK(x.size(0) == M, "wgrad: row counts differ");
+  TORCH_CHECK(pda::wgrad_supported((int)M, (int)I, (int)J), "wgrad: unsupported shape ", M, "x", I, "x", J);
+  TORCH_CHECK(dy.stride(0) % 8 == 0 && x.stride(0) % 8 == 0 &&
+                  reinterpret_cast<uintptr_t>(dy.data_ptr()) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
+              "wgrad: operands must be 16-byte aligned with row strides that are multiples of 8");
+  const c10::DeviceGuard guard(dy.device());
+  const int S = pda::wgrad_pick_slices((int)M, (int)I, (int)J);
+  auto f32 = dy.options().dtype(at::kFloat);
+  at::Tensor partial = at::empty({S, I, J}, f32);
+  at::Tensor bpartial = want_bias ? at::empty({S, I}, f32) : at::Tensor();
+  hipStream_t stream = current_stream();
+  pda::wgrad_gemm(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), partial.data_ptr<float>(),
+                  want_bias ? bpartial.data_ptr<float>() : nullptr, (int)M, (int)I, (int)J, S, stream);
+  check_launch("wgrad_gemm");
+  at::Tensor dw = at::empty({I, J}, dy.options());
+  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, pda::kBF16, dw.data_ptr(), false, stream);
+  at::Tensor db;
+  if (want_bias) {
+    db = at::empty({I}, dy.options());
+    pda::wgrad_reduce(bpartial.data_ptr<float>(), S, I, pda::kBF16, db.data_ptr(), false, stream);
+  }
+  check_launch("wgrad_reduce");
+  return {dw, db};
+}
+
 }  // namespace
 
 void bind_ops(py::module_& m) {
+  m.def("wgrad_supported", &wgrad_supported);
+  m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"));
   m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
         py::arg("bias"), py::arg("eps"), py::arg("rms"));
   m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"),

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
   constexpr int kKSteps = D / 16;
   constexpr int kDBlocks = D / 32;
   constexpr int kTileBytes = kBN * D * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q tile | dO tile]
+  // [2][Q tile | dO tile], then [2][64 x (-LSE/scale) | 64 x (-delta)] fp32 row constants
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rowc = reinterpret_cast<float*>(smem + 4 * kTileBytes);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -232,11 +234,20 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
   const int first_tile = (kt * kBM) / kBN;
   const int n_tiles = (T + kBN - 1) / kBN;
 
+  // Threads 0..63 stage -LSE/scale, threads 64..127 stage -delta of the tile's 64 queries.
+  auto load_rowc = [&](int tile) -> float {
+    if (tid >= 128) return 0.f;
+    int q = tile * kBN + (tid & 63);
+    q = q < T ? q : T - 1;
+    return tid < 64 ? -lse_row[q] * inv_scale : -delta_row[q];
+  };
   TileStager<D, kBN, kThreads> q_stage, do_stage;
   q_stage.load(q_base, tok_stride, first_tile * kBN, T - 1, tid);
   do_stage.load(do_base, o_stride, first_tile * kBN, T - 1, tid);
+  float rc_stage = load_rowc(first_tile);
   q_stage.store(smem, tid);
   do_stage.store(smem + kTileBytes, tid);
+  if (tid < 128) rowc[tid] = rc_stage;
   __syncthreads();
 
   for (int j = first_tile; j < n_tiles; ++j) {
@@ -244,9 +255,11 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
     const char* q_tile = smem + buf * 2 * kTileBytes;
     const char* do_tile = q_tile + kTileBytes;
     const bool has_next = j + 1 < n_tiles;
+    const float* rc = rowc + buf * 128;
     if (has_next) {
       q_stage.load(q_base, tok_stride, (j + 1) * kBN, T - 1, tid);
       do_stage.load(do_base, o_stride, (j + 1) * kBN, T - 1, tid);
+      rc_stage = load_rowc(j + 1);
     }
 
     if (wave_active) {
@@ -258,12 +271,13 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
         f32x16 s_acc, dp_acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          // chains end as S - LSE/scale (so exp2(c * acc) = P) and dP - delta
+          const f32x4 a = *reinterpret_cast<const f32x4*>(rc + sub * 32 + 8 * g + 4 * h);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(rc + 64 + sub * 32 + 8 * g + 4 * h);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            int q = qs + 8 * g + 4 * h + e;
-            q = q < T ? q : T - 1;
-            s_acc[4 * g + e] = -lse_row[q] * inv_scale;  // chain ends as S - LSE/scale; exp2(c * acc) = P
-            dp_acc[4 * g + e] = -delta_row[q];
+            s_acc[4 * g + e] = a[e];
+            dp_acc[4 * g + e] = d[e];
           }
         }
 #pragma unroll
@@ -308,6 +322,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
       char* nq = smem + (buf ^ 1) * 2 * kTileBytes;
       q_stage.store(nq, tid);
       do_stage.store(nq + kTileBytes, tid);
+      if (tid < 128) rowc[(buf ^ 1) * 128 + tid] = rc_stage;
     }
     __syncthreads();
   }
@@ -341,14 +356,14 @@ void attention_backward(const void* qkv, const void* out, const void* dout, cons
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, lds, stream, (const bf16_raw*)qkv,
                        (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H,
                        softmax_scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, lds, stream, (const bf16_raw*)qkv,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, lds + 1024, stream, (const bf16_raw*)qkv,
                        (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale);
   } else {
     constexpr size_t lds = 2 * 2 * kBN * 128 * 2;
     hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, block, lds, stream, (const bf16_raw*)qkv,
                        (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H,
                        softmax_scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, block, lds, stream, (const bf16_raw*)qkv,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, block, lds + 1024, stream, (const bf16_raw*)qkv,
                        (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale);
   }
 }

@@ -1,0 +1,339 @@
+// Weight-gradient GEMM for gfx950: C[I, J] = A[M, I]^T . B[M, J] with the LONG dimension M
+// (tokens) as the contraction, plus the column sums of A (the bias gradient) for free.
+//
+// Why a dedicated kernel. In dW = dY^T . X both operands are stored with the contraction
+// index as their ROW index, and the output (I x J = a weight matrix) has far fewer
+// 256 x 256 tiles than the chip has CUs (25-100 for GPT-2 Large), so the shape needs
+// split-K and transposed operand access at once. Here:
+//   * a workgroup (8 waves) owns one 256 x 256 output tile and one slice of M, so
+//     tiles x slices ~ 2 x 256 workgroups fill the 256 CUs twice over;
+//   * both operand tiles are staged as they lie in memory — 64 rows of M x 256 columns,
+//     fully coalesced 512-byte rows — and the MFMA fragments are read TRANSPOSED out of LDS
+//     with ds_read_b64_tr_b16, so no transpose pass and no strided global access exists;
+//     one XOR swizzle keeps those reads bank-conflict free;
+//   * tiles travel global -> LDS directly (global_load_lds, 1 KiB per wave-instruction, no
+//     VGPR staging and no ds_write pass — LDS store bandwidth is a third of its load
+//     bandwidth and was the limiter of a register-staged version); the swizzle is applied to
+//     the per-lane SOURCE address because the LDS destination of such a load is linear;
+//     a 4-stage LDS ring keeps three stages (96 KiB per CU) in flight behind the one being
+//     read — with one stage in flight the kernel ran at the loaded memory latency
+//     (~2 us per 64 KiB) instead of the MFMA rate; waits are counted (vmcnt(8)), barriers raw;
+//   * workgroups whose tile is in the first column block also add up their A tile's columns
+//     (one 16-byte LDS read per thread and row): that is the bias gradient, which otherwise
+//     costs a separate full read of dY;
+//   * consecutive task ids share an M slice and workgroup ids are dealt to XCDs in
+//     contiguous task ranges, so the CUs of one XCD stream the same rows of A and B
+//     through their shared L2 (affinity only, never correctness).
+// Partial tiles go to an fp32 workspace [slices][I][J]; wgrad_reduce folds the slices,
+// converts, and optionally accumulates into an existing gradient.
+#include "attention_common.h"
+#include "pda_kernels.h"
+
+namespace pda {
+namespace {
+
+using namespace attn;
+
+constexpr int kThreads = 512;
+constexpr int kTile = 256;     // output tile edge
+constexpr int kBM = 32;        // contraction rows per pipeline stage
+constexpr int kStages = 4;     // LDS ring: 3 stages (96 KiB per CU) in flight behind the one being read
+constexpr int kRowBytes = kTile * 2;
+constexpr int kTileBytes = kBM * kRowBytes;  // 16 KiB per operand tile
+constexpr int kStageBytes = 2 * kTileBytes;
+constexpr int kLoadsPerStage = 4;            // global_load_lds instructions per wave and stage
+
+// Byte offset of 16-byte chunk `chunk` (0..31) of row `row` in a [64][256] bf16 LDS tile.
+// A transposed read touches rows 4a..4a+3 x one 64-byte segment per 32 lanes; XOR-ing the
+// segment index with row & 3 spreads the four rows over the four segments of a 256-byte
+// bank row.
+__device__ __forceinline__ int wg_tile_off(int row, int chunk) {
+  return row * kRowBytes + ((chunk ^ ((row & 3) << 2)) << 4);
+}
+
+// LDS reads are issued through inline asm on purpose. While global_load_lds operations are
+// in flight the compiler cannot prove that an ordinary LDS read does not alias their
+// destination and drains the whole queue (s_waitcnt vmcnt(0)) in front of it, which would
+// serialise the ring. The asm reads are invisible to that bookkeeping; their completion is
+// awaited explicitly (counted s_waitcnt lgkmcnt + a scheduling fence) before the MFMAs.
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+template <int kOff>
+__device__ __forceinline__ s16x4 tr_read(unsigned addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(kOff));
+  return v;
+}
+
+template <int kOff>
+__device__ __forceinline__ u32x4 b128_read(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(kOff));
+  return v;
+}
+
+// Per-lane LDS byte offset (inside one operand tile) of the fragment rows for k-step 0 and
+// 32-column block `cblock`: lane (r, h) will receive
+// tile[16*kstep + 8*(j>>2) + 4*h + (j&3)][32*cblock + r], j = 0..7, from two transposed reads
+// at this offset + 8192*kstep and + 4096 (rows +8; the swizzle only looks at row & 3).
+__device__ __forceinline__ unsigned frag_base(int cblock, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int q = i >> 2, p = i & 3;
+  const int h = g >> 1;
+  const int col = cblock * 32 + 16 * (g & 1) + 4 * p;
+  return (unsigned)(wg_tile_off(4 * h + q, col >> 3) + (col & 7) * 2);
+}
+
+__device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Direct global -> LDS copy of one [32][256] bf16 tile by the 8 waves of the workgroup:
+// wave w moves rows 4w .. 4w+3, two rows (1 KiB) per instruction. The LDS destination is
+// "wave base + lane * 16" (hardware rule), so lane p lands on (row = 2i + p/32, slot p % 32);
+// it therefore FETCHES the chunk that belongs in that slot: slot ^ swizzle(row).
+__device__ __forceinline__ void stage_tile(const bf16_raw* base, int64_t ld, int row0, int col0, char* tile,
+                                           int wave, int lane) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 4 + 2 * i + (lane >> 5);
+    const int chunk = (lane & 31) ^ ((row & 3) << 2);
+    const bf16_raw* src = base + int64_t(row0 + row) * ld + col0 + chunk * 8;
+    char* dst = tile + (wave * 4 + 2 * i) * kRowBytes;  // wave-uniform
+    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restrict__ A, int64_t lda,
+                                                         const bf16_raw* __restrict__ B, int64_t ldb,
+                                                         float* __restrict__ c_partial,
+                                                         float* __restrict__ bias_partial, int M, int I,
+                                                         int J, int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 2, wj = wave & 3;  // 2 x 4 waves: 128 (i) x 64 (j) per wave
+  const int h = lane >> 5, r = lane & 31;
+
+  // ---- task mapping -------------------------------------------------------------------
+  const int tiles_j = J / kTile, tiles_i = I / kTile;
+  const int n_tiles = tiles_i * tiles_j;
+  const int n_tasks = n_tiles * S;
+  // Workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous task range.
+  const int q8 = n_tasks / 8, r8 = n_tasks % 8;
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int task = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+  const int slice = task / n_tiles;
+  const int tile = task % n_tiles;
+  const int ti = tile / tiles_j, tj = tile % tiles_j;
+
+  const int steps_total = M / kBM;
+  const int step_lo = int(int64_t(steps_total) * slice / S);
+  const int step_hi = int(int64_t(steps_total) * (slice + 1) / S);
+  const int n_steps = step_hi - step_lo;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const bool do_bias = bias_partial != nullptr && tj == 0;  // workgroup-uniform
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  const unsigned smem_base = lds_addr(smem);
+  unsigned a_base[4], b_base[2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) a_base[a] = frag_base(wi * 4 + a, lane);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) b_base[b] = frag_base(wj * 2 + b, lane);
+  const unsigned bias_off = (unsigned)wg_tile_off(tid >> 5, tid & 31);  // rows +16: +8192 bytes
+
+  auto issue = [&](int t, int slot_idx) {
+    char* slot = smem + slot_idx * kStageBytes;
+    stage_tile(A, lda, (step_lo + t) * kBM, ti * kTile, slot, wave, lane);
+    stage_tile(B, ldb, (step_lo + t) * kBM, tj * kTile, slot + kTileBytes, wave, lane);
+  };
+#pragma unroll
+  for (int t = 0; t < kStages - 1; ++t)
+    if (t < n_steps) issue(t, t);
+
+  for (int t0 = 0; t0 < n_steps; t0 += kStages) {
+#pragma unroll
+    for (int u = 0; u < kStages; ++u) {
+      const int t = t0 + u;
+      if (t >= n_steps) break;  // workgroup-uniform
+      // Retire this wave's loads of stage t, leaving the younger stages in flight (each stage
+      // is kLoadsPerStage instructions per wave), then meet the other waves: after the barrier
+      // every wave's part of stage t has landed AND every wave is done reading stage t-1,
+      // whose slot the next issue overwrites.
+      const int younger = n_steps - 1 - t;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + kStages - 1 < n_steps) issue(t + kStages - 1, (u + kStages - 1) % kStages);
+
+      const unsigned a_tile = smem_base + u * kStageBytes;
+      const unsigned b_tile = a_tile + kTileBytes;
+      s16x4 al[2][4], ah[2][4], bl[2][2], bh[2][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        al[0][a] = tr_read<0>(a_tile + a_base[a]);
+        ah[0][a] = tr_read<4096>(a_tile + a_base[a]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bl[0][b] = tr_read<0>(b_tile + b_base[b]);
+        bh[0][b] = tr_read<4096>(b_tile + b_base[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        al[1][a] = tr_read<8192>(a_tile + a_base[a]);
+        ah[1][a] = tr_read<12288>(a_tile + a_base[a]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bl[1][b] = tr_read<8192>(b_tile + b_base[b]);
+        bh[1][b] = tr_read<12288>(b_tile + b_base[b]);
+      }
+      u32x4 bias_rows[2];
+      if (do_bias) {  // column sums of the A tile: thread owns chunk (tid & 31) of rows (tid >> 5) + 16 i
+        bias_rows[0] = b128_read<0>(a_tile + bias_off);
+        bias_rows[1] = b128_read<8192>(a_tile + bias_off);
+        asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");  // the 12 reads of k-step 0
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(join(al[0][a], ah[0][a]), join(bl[0][b], bh[0][b]), acc[a][b]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(join(al[1][a], ah[1][a]), join(bl[1][b], bh[1][b]), acc[a][b]);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            bsum[2 * w] += bf16_lo(bias_rows[i][w]);
+            bsum[2 * w + 1] += bf16_hi(bias_rows[i][w]);
+          }
+      }
+    }
+  }
+  __syncthreads();  // the ring is reused below
+
+  // ---- epilogue: fp32 partial tile ------------------------------------------------------
+  // acc[a][b] register e of lane (r, h): row i = 32*(4*wi + a) + acc_row(e, h), column j = 32*(2*wj + b) + r.
+  float* cp = c_partial + (int64_t(slice) * I + int64_t(ti) * kTile) * J + int64_t(tj) * kTile;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * (4 * wi + a) + acc_row(e, h);
+        const int j = 32 * (2 * wj + b) + r;
+        cp[int64_t(i) * J + j] = acc[a][b][e];
+      }
+
+  if (do_bias) {  // fold the 16 threads that share a chunk (same tid & 31) through LDS
+    float* red = reinterpret_cast<float*>(smem);  // [16][256]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 5) * kTile + (tid & 31) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < kTile) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += red[g * kTile + tid];
+      bias_partial[int64_t(slice) * I + ti * kTile + tid] = s;
+    }
+  }
+}
+
+// out[n] (+)= sum_s partial[s][n], n over `numel` elements, 4 per thread.
+template <typename OutT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S,
+                                                           int64_t numel, OutT* __restrict__ out,
+                                                           bool accumulate) {
+  const int64_t stride = int64_t(gridDim.x) * 256 * 4;
+  for (int64_t n = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 4; n < numel; n += stride) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(partial + n);
+    for (int k = 1; k < S; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(partial + int64_t(k) * numel + n);
+      s += v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = s[e];
+      if (accumulate) v += VecIO<OutT>::load1(out + n + e);
+      VecIO<OutT>::store1(out + n + e, v);
+    }
+  }
+}
+
+}  // namespace
+
+int wgrad_pick_slices(int M, int I, int J) {
+  const int n_tiles = (I / kTile) * (J / kTile);
+  const int steps = M / kBM;
+  int best = 1;
+  double best_score = -1.0;
+  for (int s = 1; s <= 16 && s <= steps; ++s) {
+    const int tasks = n_tiles * s;
+    const int rounds = (tasks + 255) / 256;
+    const double score = double(tasks) / (rounds * 256.0) - 0.015 * s;
+    if (score > best_score) {
+      best_score = score;
+      best = s;
+    }
+  }
+  return best;
+}
+
+bool wgrad_supported(int M, int I, int J) {
+  return M >= kBM && M % kBM == 0 && I % kTile == 0 && J % kTile == 0 && I > 0 && J > 0;
+}
+
+void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
+                float* bias_partial, int M, int I, int J, int S, hipStream_t stream) {
+  const int n_tasks = (I / kTile) * (J / kTile) * S;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kStages * kStageBytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_tasks), dim3(kThreads), kStages * kStageBytes, stream,
+                     (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
+}
+
+void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
+                  hipStream_t stream) {
+  int64_t blocks = ceil_div(numel, 1024);
+  if (blocks > 2048) blocks = 2048;
+  if (out_dtype == kBF16)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, stream, partial, S,
+                       numel, (bf16_raw*)out, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, partial, S,
+                       numel, (float*)out, accumulate);
+}
+
+}  // namespace pda

@@ -218,23 +218,34 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
   }
 }
 
-// out[c] (+)= sum_r partial[r][c]. Block = 64 columns x 4 row groups.
+// out[c] (+)= sum_r partial[r][c]. Block = 64 columns x 16 row groups (1024 threads): the
+// partial matrix is small (<= 512 x d fp32) and latency-bound, so every thread keeps
+// several independent loads in flight and the row groups are folded through LDS.
+constexpr int kReduceGroups = 16;
 template <typename OutT>
-__global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ partial,
-                                                                   int partial_rows, int d,
-                                                                   OutT* __restrict__ out,
-                                                                   bool accumulate) {
-  __shared__ float sm[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+__global__ __launch_bounds__(64 * kReduceGroups) void reduce_partials_kernel(
+    const float* __restrict__ partial, int partial_rows, int d, OutT* __restrict__ out, bool accumulate) {
+  __shared__ float sm[kReduceGroups][64];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lane;
   const int rg = threadIdx.x >> 6;
-  float acc = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < d) {
-    for (int r = rg; r < partial_rows; r += 4) acc += partial[int64_t(r) * d + c];
+    int r = rg;
+    for (; r + 3 * kReduceGroups < partial_rows; r += 4 * kReduceGroups) {
+      a0 += partial[int64_t(r) * d + c];
+      a1 += partial[int64_t(r + kReduceGroups) * d + c];
+      a2 += partial[int64_t(r + 2 * kReduceGroups) * d + c];
+      a3 += partial[int64_t(r + 3 * kReduceGroups) * d + c];
+    }
+    for (; r < partial_rows; r += kReduceGroups) a0 += partial[int64_t(r) * d + c];
   }
-  sm[rg][threadIdx.x & 63] = acc;
+  sm[rg][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rg == 0 && c < d) {
-    float t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < kReduceGroups; ++i) t += sm[i][lane];
     if (accumulate) t += VecIO<OutT>::load1(out + c);
     VecIO<OutT>::store1(out + c, t);
   }
@@ -337,7 +348,7 @@ void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const v
 void norm_reduce_partials(const float* dw_partial, const float* db_partial, int partial_rows, int d,
                           DType out_dtype, void* dweight, void* dbias, bool accumulate,
                           hipStream_t stream) {
-  dim3 grid((d + 63) / 64), block(kThreads);
+  dim3 grid((d + 63) / 64), block(64 * kReduceGroups);
   for (int which = 0; which < 2; ++which) {
     const float* src = which == 0 ? dw_partial : db_partial;
     void* dst = which == 0 ? dweight : dbias;

@@ -93,6 +93,18 @@ void attention_backward(const void* qkv, const void* out, const void* dout, cons
                         float* delta, void* dqkv, int B, int T, int H, int D, float softmax_scale,
                         hipStream_t stream);
 
+// ------------------------------------------------------------- Weight gradient --
+// C[I, J] = A[M, I]^T . B[M, J] (bf16 operands, row strides lda / ldb in elements) with the
+// contraction M split over S slices: fp32 partials [S][I][J] (+ optional column sums of A,
+// [S][I], the bias gradient), folded by wgrad_reduce. Needs M % 64 == 0, I % 256 == 0,
+// J % 256 == 0 (wgrad_supported); wgrad_pick_slices chooses S to fill the 256 CUs.
+bool wgrad_supported(int M, int I, int J);
+int wgrad_pick_slices(int M, int I, int J);
+void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
+                float* bias_partial, int M, int I, int J, int S, hipStream_t stream);
+void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
+                  hipStream_t stream);
+
 // ----------------------------------------------------------------- Utilities --
 // dst(fp32) += src(bf16) * scale, and plain casts, for main-grad accumulation.
 void accumulate_bf16_into_f32(const void* src_bf16, float* dst, int64_t n, float scale, hipStream_t stream);

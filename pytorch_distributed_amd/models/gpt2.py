@@ -51,9 +51,10 @@ class MyGPT2Attention(nn.Module):
         self.resid_dropout = nn.Dropout(p=config.resid_pdrop)
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        qkv = self.c_attn(hidden_states)  # [B, T, 3d], consumed in place by the attention kernel
+        # [B, T, 3d], consumed in place by the attention kernel
+        qkv = ops.linear(hidden_states, self.c_attn.weight, self.c_attn.bias)
         ctx = ops.causal_attention(qkv, self.num_heads, dropout_p=self.attn_pdrop, training=self.training)
-        return self.resid_dropout(self.c_proj(ctx))
+        return self.resid_dropout(ops.linear(ctx, self.c_proj.weight, self.c_proj.bias))
 
 
 class MyGPT2MLP(nn.Module):
@@ -70,7 +71,8 @@ class MyGPT2MLP(nn.Module):
         self.dropout = nn.Dropout(p=config.resid_pdrop)
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        return self.dropout(self.c_proj(ops.gelu_new(self.c_fc(hidden_states))))
+        u = ops.linear(hidden_states, self.c_fc.weight, self.c_fc.bias)
+        return self.dropout(ops.linear(ops.gelu_new(u), self.c_proj.weight, self.c_proj.bias))
 
 
 class MyGPT2Block(nn.Module):

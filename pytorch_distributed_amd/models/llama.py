@@ -85,8 +85,8 @@ class LlamaAttention(nn.Module):
         self.c_proj = nn.Linear(config.n_embd, config.n_embd, bias=False)
 
     def forward(self, x, cos, sin):
-        qkv = _RopePacked.apply(self.wqkv(x), cos, sin, self.num_heads)
-        return self.c_proj(ops.causal_attention(qkv, self.num_heads))
+        qkv = _RopePacked.apply(ops.linear(x, self.wqkv.weight), cos, sin, self.num_heads)
+        return ops.linear(ops.causal_attention(qkv, self.num_heads), self.c_proj.weight)
 
 
 class LlamaMLP(nn.Module):
@@ -96,7 +96,7 @@ class LlamaMLP(nn.Module):
         self.down = nn.Linear(config.intermediate_size, config.n_embd, bias=False)
 
     def forward(self, x):
-        return self.down(ops.swiglu(self.gate_up(x)))
+        return ops.linear(ops.swiglu(ops.linear(x, self.gate_up.weight)), self.down.weight)
 
 
 class LlamaBlock(nn.Module):
