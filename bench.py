@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--model", default="gpt2-large")
     ap.add_argument("--seq-len", type=int, default=1024)
     ap.add_argument("--batch-per-gpu", type=int, default=32, help="sequences per GPU per optimizer step")
-    ap.add_argument("--micro-batch", type=int, default=16, help="sequences per forward/backward")
+    ap.add_argument("--micro-batch", type=int, default=32, help="sequences per forward/backward")
     ap.add_argument("--mode", choices=["fsdp", "ddp"], default="fsdp",
                     help="data-parallel flavour for --gpus > 1")
     ap.add_argument("--strategy", default="FULL_SHARD", choices=["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"])

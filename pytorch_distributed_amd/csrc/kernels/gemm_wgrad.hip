@@ -28,6 +28,7 @@
 // converts, and optionally accumulates into an existing gradient.
 #include "attention_common.h"
 #include "pda_kernels.h"
+#include <stdlib.h>
 
 namespace pda {
 namespace {
@@ -91,24 +92,23 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// Direct global -> LDS copy of one [32][256] bf16 tile by the 8 waves of the workgroup:
-// wave w moves rows 4w .. 4w+3, two rows (1 KiB) per instruction. The LDS destination is
-// "wave base + lane * 16" (hardware rule), so lane p lands on (row = 2i + p/32, slot p % 32);
-// it therefore FETCHES the chunk that belongs in that slot: slot ^ swizzle(row).
-__device__ __forceinline__ void stage_tile(const bf16_raw* base, int64_t ld, int row0, int col0, char* tile,
-                                           int wave, int lane) {
+// Direct global -> LDS copy of 16 rows (one MFMA k-step) of a [32][256] bf16 tile by the 8
+// waves of the workgroup: wave w moves rows 16*half + 2w and + 2w + 1 (1 KiB) in one
+// instruction. The LDS destination is "wave base + lane * 16" (hardware rule), so lane p lands
+// on (row + p/32, slot p % 32); it therefore FETCHES the chunk that belongs in that slot:
+// slot ^ swizzle(row).
+__device__ __forceinline__ void stage_half(const bf16_raw* base, int64_t ld, int row0, int col0, char* tile,
+                                           int half, int wave, int lane) {
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 4 + 2 * i + (lane >> 5);
-    const int chunk = (lane & 31) ^ ((row & 3) << 2);
-    const bf16_raw* src = base + int64_t(row0 + row) * ld + col0 + chunk * 8;
-    char* dst = tile + (wave * 4 + 2 * i) * kRowBytes;  // wave-uniform
-    __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
-  }
+  const int row = 16 * half + 2 * wave + (lane >> 5);
+  const int chunk = (lane & 31) ^ ((row & 3) << 2);
+  const bf16_raw* src = base + int64_t(row0 + row) * ld + col0 + chunk * 8;
+  char* dst = tile + (16 * half + 2 * wave) * kRowBytes;  // wave-uniform
+  __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
 }
 
+template <int kMode>
 __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restrict__ A, int64_t lda,
                                                          const bf16_raw* __restrict__ B, int64_t ldb,
                                                          float* __restrict__ c_partial,
@@ -158,74 +158,111 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
   for (int b = 0; b < 2; ++b) b_base[b] = frag_base(wj * 2 + b, lane);
   const unsigned bias_off = (unsigned)wg_tile_off(tid >> 5, tid & 31);  // rows +16: +8192 bytes
 
+  // Loads of one stage, oldest first: A rows 0-15, B rows 0-15 (k-step 0), then A and B rows
+  // 16-31 (k-step 1) — so "all but the last two" of a stage means its k-step 0 has landed.
   auto issue = [&](int t, int slot_idx) {
     char* slot = smem + slot_idx * kStageBytes;
-    stage_tile(A, lda, (step_lo + t) * kBM, ti * kTile, slot, wave, lane);
-    stage_tile(B, ldb, (step_lo + t) * kBM, tj * kTile, slot + kTileBytes, wave, lane);
+    const int row0 = (step_lo + t) * kBM;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      stage_half(A, lda, row0, ti * kTile, slot, half, wave, lane);
+      stage_half(B, ldb, row0, tj * kTile, slot + kTileBytes, half, wave, lane);
+    }
   };
 #pragma unroll
   for (int t = 0; t < kStages - 1; ++t)
     if (t < n_steps) issue(t, t);
+
+  // Fragments of k-step 0 of the stage about to be multiplied; always fetched one stage ahead
+  // (before the barrier that opens that stage), so the matrix pipe has work the moment the
+  // barrier releases instead of idling for an LDS round trip.
+  s16x4 cl[4], ch[4], dl[2], dh[2];
+  auto read_k0 = [&](int slot_idx) {
+    const unsigned a_tile = smem_base + slot_idx * kStageBytes;
+    const unsigned b_tile = a_tile + kTileBytes;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      cl[a] = tr_read<0>(a_tile + a_base[a]);
+      ch[a] = tr_read<4096>(a_tile + a_base[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      dl[b] = tr_read<0>(b_tile + b_base[b]);
+      dh[b] = tr_read<4096>(b_tile + b_base[b]);
+    }
+  };
+  {
+    // k-step 0 of stage 0: this wave's first two loads, then everyone's.
+    if (n_steps >= 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n_steps == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_k0(0);
+  }
 
   for (int t0 = 0; t0 < n_steps; t0 += kStages) {
 #pragma unroll
     for (int u = 0; u < kStages; ++u) {
       const int t = t0 + u;
       if (t >= n_steps) break;  // workgroup-uniform
-      // Retire this wave's loads of stage t, leaving the younger stages in flight (each stage
-      // is kLoadsPerStage instructions per wave), then meet the other waves: after the barrier
-      // every wave's part of stage t has landed AND every wave is done reading stage t-1,
-      // whose slot the next issue overwrites.
+      // Retire this wave's loads of stage t and of k-step 0 of stage t+1, leaving everything
+      // younger in flight, then meet the other waves: after the barrier every wave's part of
+      // those rows has landed AND every wave is done reading stage t-1, whose slot the next
+      // issue overwrites.
       const int younger = n_steps - 1 - t;
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (kMode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (t + kStages - 1 < n_steps) issue(t + kStages - 1, (u + kStages - 1) % kStages);
+      if (kMode != 1 && t + kStages - 1 < n_steps) issue(t + kStages - 1, (u + kStages - 1) % kStages);
+      if (kMode == 2) continue;
 
       const unsigned a_tile = smem_base + u * kStageBytes;
       const unsigned b_tile = a_tile + kTileBytes;
-      s16x4 al[2][4], ah[2][4], bl[2][2], bh[2][2];
+      s16x4 el[4], eh[4], fl[2], fh[2];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        al[0][a] = tr_read<0>(a_tile + a_base[a]);
-        ah[0][a] = tr_read<4096>(a_tile + a_base[a]);
+        el[a] = tr_read<8192>(a_tile + a_base[a]);
+        eh[a] = tr_read<12288>(a_tile + a_base[a]);
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        bl[0][b] = tr_read<0>(b_tile + b_base[b]);
-        bh[0][b] = tr_read<4096>(b_tile + b_base[b]);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        al[1][a] = tr_read<8192>(a_tile + a_base[a]);
-        ah[1][a] = tr_read<12288>(a_tile + a_base[a]);
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        bl[1][b] = tr_read<8192>(b_tile + b_base[b]);
-        bh[1][b] = tr_read<12288>(b_tile + b_base[b]);
+        fl[b] = tr_read<8192>(b_tile + b_base[b]);
+        fh[b] = tr_read<12288>(b_tile + b_base[b]);
       }
       u32x4 bias_rows[2];
       if (do_bias) {  // column sums of the A tile: thread owns chunk (tid & 31) of rows (tid >> 5) + 16 i
         bias_rows[0] = b128_read<0>(a_tile + bias_off);
         bias_rows[1] = b128_read<8192>(a_tile + bias_off);
-        asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");  // the 12 reads of k-step 0
+        asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");  // k-step 0 fragments (read a stage ago)
       } else {
         asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = join(cl[a], ch[a]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bfr[b] = join(dl[b], dh[b]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(af[a], bfr[b], acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (younger >= 1) {  // k-step 0 of stage t+1 (landed before this stage's barrier)
+        read_k0((u + 1) % kStages);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(join(al[0][a], ah[0][a]), join(bl[0][b], bh[0][b]), acc[a][b]);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(join(al[1][a], ah[1][a]), join(bl[1][b], bh[1][b]), acc[a][b]);
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(join(el[a], eh[a]), join(fl[b], fh[b]), acc[a][b]);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -237,6 +274,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
       }
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // the ring is reused below
 
   // ---- epilogue: fp32 partial tile ------------------------------------------------------
@@ -314,13 +352,16 @@ bool wgrad_supported(int M, int I, int J) {
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream) {
   const int n_tasks = (I / kTile) * (J / kTile) * S;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kStages * kStageBytes);
-    attr_set = true;
+  static int mode = -1;
+  if (mode < 0) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    const char* e = getenv("PDA_WGRAD_MODE");
+    mode = e ? atoi(e) : 0;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)n_tasks), dim3(kThreads), kStages * kStageBytes, stream,
+  auto kern = mode == 1 ? wgrad_kernel<1> : mode == 2 ? wgrad_kernel<2> : wgrad_kernel<0>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(kThreads), kStages * kStageBytes, stream,
                      (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
 }
 

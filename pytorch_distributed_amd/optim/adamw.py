@@ -54,9 +54,12 @@ class FusedAdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
-    def step(self, closure=None, zero_grad: bool = False, grad_scale: float = 1.0):
+    def step(self, closure=None, zero_grad: bool = False, grad_scale: float = 1.0, set_to_none: bool = True):
         """One AdamW update. ``grad_scale`` multiplies every gradient first (e.g. ``1/world``
-        after a summing reduction); ``zero_grad=True`` also zeroes the gradients in place."""
+        after a summing reduction). ``zero_grad=True`` also clears the gradients: a gradient
+        that owns its memory is dropped (``set_to_none``; the next backward then moves the
+        fresh gradient in instead of adding to zeros), a gradient that is a view of a reducer's
+        flat bucket or an fp32 main-grad buffer is zeroed inside the update kernel."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -79,7 +82,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 step_val = int(st["step"].item())
                 # Shard gradients of the sharded-data-parallel runtime are re-created by every
                 # reduction: drop them after the update instead of zeroing them.
-                drop = zero_grad and getattr(p, "_pda_free_grad_after_step", False)
+                drop = zero_grad and grad is p.grad and (
+                    getattr(p, "_pda_free_grad_after_step", False)
+                    or (set_to_none and not getattr(p, "_pda_grad_is_view", False)))
                 if drop:
                     drop_after.append(p)
                 if p.is_cuda and not _ext.force_reference():
