@@ -104,7 +104,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if rebuilt or force or not TARGET.exists():
         link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(TARGET), *objs,
                 f"-L{torch_lib}", f"-Wl,-rpath,{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu",
-                "-ltorch_hip", "-ltorch", "-ltorch_python", "-lpthread"]
+                "-ltorch_hip", "-ltorch", "-ltorch_python",
+                # the hipBLASLt that PyTorch itself loaded (linking /opt/rocm's copy would pull a second
+                # HIP runtime into the process)
+                str(Path(torch_lib) / "libhipblaslt.so"), "-lpthread"]
         if verbose:
             print("[build]", " ".join(link), flush=True)
         proc = subprocess.run(link, capture_output=True, text=True)

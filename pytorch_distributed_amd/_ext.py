@@ -21,6 +21,9 @@ def load():
     global _ext, _ext_error
     if _ext is None and _ext_error is None:
         try:
+            # PyTorch first: _C must bind to the HIP runtime and hipBLASLt that libtorch_hip
+            # already mapped (by SONAME), not to a second copy found through its own run path.
+            import torch  # noqa: F401
             _ext = importlib.import_module("pytorch_distributed_amd._C")
         except Exception as exc:  # missing file, unresolved symbol, ...
             _ext_error = exc

@@ -26,6 +26,8 @@
 #include "attention_common.h"
 #include "pda_kernels.h"
 
+#include <type_traits>
+
 namespace pda {
 namespace {
 
@@ -36,8 +38,13 @@ constexpr int kBM = 128;  // rows owned by a workgroup (queries in dq, keys in d
 constexpr int kBN = 64;   // rows per streamed tile (keys in dq, queries in dkv)
 
 // ============================================================================ dQ
+// amdgpu_waves_per_eu: with a register budget of at most 256 per wave the compiler keeps MFMA
+// accumulators in ordinary VGPRs. Left at the launch-bounds default (one wave per SIMD, 512
+// registers) it parks them in AGPRs and moves every S / dP / dS element across with
+// v_accvgpr_read/write — 130-160 extra VALU instructions per 16 MFMAs, which made these
+// kernels VALU-bound at 20 % matrix-pipe utilisation.
 template <int D>
-__global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 2 : 1))) void attn_bwd_dq_kernel(
     const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ out,
     const bf16_raw* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta_out,
     bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale) {
@@ -135,14 +142,27 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(
       }
       const int key0 = j * kBN;
       const bool diag = key0 + kBN - 1 > q0;  // wave-uniform
+      // dS^T = P^T (dP^T - delta), without the softmax scale. Two elements per packed fp32
+      // instruction; the causal mask is only evaluated on tiles that straddle the diagonal.
+      const f32x2 c2 = {c, c}, l2 = {lse2, lse2};
+      auto softmax_grad = [&](auto masked) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f(s_acc[kb][i] * c - lse2);
-          if (diag && key0 + kb * 32 + acc_row(i, h) > q_row) p = 0.f;
-          s_acc[kb][i] = p * dp_acc[kb][i];  // dS^T (without the softmax scale)
-        }
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 e = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} * c2 - l2;
+            f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            if (decltype(masked)::value) {
+              if (key0 + kb * 32 + acc_row(i, h) > q_row) p[0] = 0.f;
+              if (key0 + kb * 32 + acc_row(i + 1, h) > q_row) p[1] = 0.f;
+            }
+            const f32x2 ds = p * f32x2{dp_acc[kb][i], dp_acc[kb][i + 1]};
+            s_acc[kb][i] = ds[0];
+            s_acc[kb][i + 1] = ds[1];
+          }
+      };
+      if (__builtin_expect(diag, 0)) softmax_grad(std::true_type{});
+      else softmax_grad(std::false_type{});
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const f32x16& a = s_acc[s >> 1];
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dq_kernel(
 
 // ========================================================================= dK / dV
 template <int D>
-__global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 2 : 1))) void attn_bwd_dkv_kernel(
     const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale) {
   constexpr int kKSteps = D / 16;
@@ -292,14 +312,29 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_dkv_kernel(
         }
         const bool diag = qs < key0 + 31;          // wave-uniform: some (q, key) pairs are masked
         const bool tail = qs + 31 >= T;            // wave-uniform: padding queries in this sub-tile
+        // P and dS = P (dP - delta), two elements per packed fp32 instruction. Only tiles on the
+        // diagonal or past the end of the sequence evaluate the mask (separate code paths:
+        // folded into one, the per-element compares ran on every tile).
+        const f32x2 c2 = {c, c};
+        auto softmax_grad = [&](auto masked) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int q = qs + acc_row(i, h);
-          float p = __builtin_amdgcn_exp2f(s_acc[i] * c);
-          if ((diag && q < key) || (tail && q >= T)) p = 0.f;
-          s_acc[i] = p;
-          dp_acc[i] = p * dp_acc[i];
-        }
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 e = f32x2{s_acc[i], s_acc[i + 1]} * c2;
+            f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            if (decltype(masked)::value) {
+              const int q = qs + acc_row(i, h);
+              if (q < key || q >= T) p[0] = 0.f;
+              if (q + 1 < key || q + 1 >= T) p[1] = 0.f;
+            }
+            const f32x2 ds = p * f32x2{dp_acc[i], dp_acc[i + 1]};
+            s_acc[i] = p[0];
+            s_acc[i + 1] = p[1];
+            dp_acc[i] = ds[0];
+            dp_acc[i + 1] = ds[1];
+          }
+        };
+        if (__builtin_expect(diag || tail, 0)) softmax_grad(std::true_type{});
+        else softmax_grad(std::false_type{});
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int o = 8 * s;

@@ -35,8 +35,12 @@ constexpr int kWaves = 4;
 constexpr int kBM = 128;  // queries per workgroup
 constexpr int kBN = 64;   // keys per tile
 
+// amdgpu_waves_per_eu(3) for D = 64: a register budget of 170 per wave keeps the MFMA
+// accumulators in ordinary VGPRs (with the launch-bounds default of 512 the compiler parks
+// them in AGPRs and copies every score across for the softmax) and lets three workgroups
+// share a CU.
 template <int D>
-__global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const bf16_raw* __restrict__ qkv,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 1))) void attn_fwd_kernel(const bf16_raw* __restrict__ qkv,
                                                             bf16_raw* __restrict__ out,
                                                             float* __restrict__ lse_out, int B, int T,
                                                             int H, float scale) {
@@ -124,31 +128,44 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const bf16_raw* __re
             if (key > q_row) s_acc[kb][i] = -INFINITY;
           }
       }
-      // ---- online softmax ---------------------------------------------------
+      // ---- online softmax (two elements per packed fp32 instruction) -----------
       float mx = s_acc[0][0];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_acc[kb][i]);
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s_acc[kb][i], s_acc[kb][i + 1]));  // v_max3_f32
       mx = lane_pair_max(mx);
       const float m_new = fmaxf(m_run, mx);  // finite: key 0 is visible to every query
+      const bool grew = m_new > m_run;
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
       const float mc = m_new * c;
       m_run = m_new;
-      float psum = 0.f;
+      const f32x2 c2 = {c, c}, mc2 = {mc, mc};
+      f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(s_acc[kb][i] * c - mc);
-          s_acc[kb][i] = p;
-          psum += p;
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 e = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} * c2 - mc2;
+          const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          s_acc[kb][i] = p[0];
+          s_acc[kb][i + 1] = p[1];
+          psum2 += p;
         }
-      l_run = l_run * alpha + psum;
+      l_run = l_run * alpha + (psum2[0] + psum2[1]);
+      // Rescale the output accumulator only when some row's running max moved (alpha == 1
+      // everywhere otherwise, which is the common case once the first tiles are behind).
+      if (__builtin_amdgcn_ballot_w64(grew) != 0) {  // wave-uniform
+        const f32x2 a2 = {alpha, alpha};
 #pragma unroll
-      for (int db = 0; db < kDBlocks; ++db)
+        for (int db = 0; db < kDBlocks; ++db)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o_acc[db][i] *= alpha;
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 o = f32x2{o_acc[db][i], o_acc[db][i + 1]} * a2;
+            o_acc[db][i] = o[0];
+            o_acc[db][i + 1] = o[1];
+          }
+      }
       // ---- O^T += V^T . P^T ---------------------------------------------------
 #pragma unroll
       for (int s = 0; s < 4; ++s) {

@@ -1,6 +1,6 @@
 // Python module `pytorch_distributed_amd._C`: one shared object holding the
 // gfx950 kernels' bindings and the native runtime (gradient reducer, flat
-// parameter sharding units, token-shard loader, range tracer).
+// parameter sharding units, token-shard loader, range tracer, GEMM planner).
 #include <torch/extension.h>
 
 namespace py = pybind11;
@@ -10,6 +10,9 @@ void bind_reducer(py::module_& m);
 void bind_fsdp(py::module_& m);
 void bind_loader(py::module_& m);
 void bind_tracer(py::module_& m);
+namespace pda {
+void bind_gemm(py::module_& m);
+}
 
 PYBIND11_MODULE(_C, m) {
   m.doc() = "MI355X-native kernels and runtime for pytorch_distributed_amd";
@@ -19,4 +22,5 @@ PYBIND11_MODULE(_C, m) {
   bind_fsdp(m);
   bind_loader(m);
   bind_tracer(m);
+  pda::bind_gemm(m);
 }

@@ -1,0 +1,313 @@
+// GEMM planner: bf16 matrix products with fused epilogues on hipBLASLt, with the algorithm
+// for every distinct problem chosen by measurement the first time the problem is seen.
+//
+// The forward and data-gradient GEMMs of a transformer are plain library GEMMs (the
+// weight-gradient shape has its own kernel, kernels/gemm_wgrad.hip). Two things are left on
+// the table when they are issued through a generic matmul call:
+//   * the library's default heuristic is regularly 5-15 % off its own best kernel on gfx950
+//     for the tall shapes of training (M = tokens = 16-64 K);
+//   * a bias add run as its own kernel costs a full HBM round trip of the output; the library
+//     applies it in the GEMM epilogue. (Its GELU epilogues are not used: on this library build
+//     GELU_AUX has no bf16 kernel at all and DGELU runs 4x slower than GEMM + a separate
+//     GELU' kernel — measured with tools/lt_probe.py — so GELU stays in kernels/activations.hip.)
+// The planner therefore keeps one plan per (shape, layout, epilogue): the matmul descriptor,
+// the matrix layouts and the winning algorithm among the heuristic's candidates, timed
+// in place on the caller's stream with the caller's operands (every epilogue used here is
+// idempotent, so re-running a candidate is harmless). Plans live for the life of the process.
+//
+// All matrices are ROW-major with unit column stride and an arbitrary row stride; hipBLASLt
+// is column-major, so out[M,N] = A'[M,K] . B'[K,N] is issued as out^T = B'^T . A'^T.
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <hipblaslt/hipblaslt.h>
+#include <torch/extension.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace pda {
+namespace {
+
+#define PDA_LT_CHECK(expr)                                                                      \
+  do {                                                                                          \
+    hipblasStatus_t st_ = (expr);                                                               \
+    TORCH_CHECK(st_ == HIPBLAS_STATUS_SUCCESS, "hipBLASLt call failed (status ", int(st_), "): ", #expr); \
+  } while (0)
+
+#define PDA_HIP_CHECK(expr)                                                                 \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    TORCH_CHECK(e_ == hipSuccess, "HIP call failed: ", hipGetErrorString(e_), " in ", #expr); \
+  } while (0)
+
+enum Epilogue : int {
+  kNone = 0,          // out = A'B'
+  kBias = 1,          // out = A'B' + bias
+};
+
+struct Key {
+  int device;
+  int64_t m, n, k, lda, ldb, ldo;
+  bool trans_a, trans_b;
+  int epilogue;
+  bool operator<(const Key& o) const {
+    return std::tie(device, m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue) <
+           std::tie(o.device, o.m, o.n, o.k, o.lda, o.ldb, o.ldo, o.trans_a, o.trans_b, o.epilogue);
+  }
+};
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lo = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t workspace = 0;
+  int candidates = 0;
+  int chosen = 0;
+  float best_us = 0.f, first_us = 0.f;
+};
+
+struct Stats {
+  int64_t plans = 0, tuned = 0, calls = 0;
+};
+
+class Planner {
+ public:
+  static Planner& get() {
+    static Planner* p = new Planner();  // never destroyed: library handles outlive static teardown order
+    return *p;
+  }
+
+  bool tuning = true;
+  int max_candidates = 24;
+  int timed_runs = 3;
+  size_t workspace_limit = size_t(64) << 20;
+
+  void run(const at::Tensor& a, bool trans_a, const at::Tensor& b, bool trans_b, at::Tensor& out, int epilogue,
+           const void* bias) {
+    const int device = a.get_device();
+    const int64_t m = out.size(0), n = out.size(1);
+    const int64_t k = trans_a ? a.size(0) : a.size(1);
+    Key key{device, m, n, k, a.stride(0), b.stride(0), out.stride(0), trans_a, trans_b, epilogue};
+    hipStream_t stream = c10::hip::getCurrentHIPStream().stream();
+    std::lock_guard<std::mutex> lock(mu_);
+    hipblasLtHandle_t handle = handle_for(device);
+    void* ws = workspace_for(device);
+    auto it = plans_.find(key);
+    if (it == plans_.end()) it = plans_.emplace(key, make_plan(handle, key)).first;
+    Plan& plan = it->second;
+    set_pointers(plan, epilogue, bias);
+    if (plan.candidates < 0) choose(handle, plan, a, b, out, ws, stream);
+    launch(handle, plan, plan.algo, a, b, out, ws, stream);
+    ++stats_.calls;
+  }
+
+  py::dict stats() {
+    std::lock_guard<std::mutex> lock(mu_);
+    py::dict d;
+    d["plans"] = stats_.plans;
+    d["tuned"] = stats_.tuned;
+    d["calls"] = stats_.calls;
+    py::list rows;
+    for (auto& kv : plans_) {
+      const Key& k = kv.first;
+      const Plan& p = kv.second;
+      rows.append(py::make_tuple(k.m, k.n, k.k, k.trans_a, k.trans_b, k.epilogue, p.candidates, p.chosen,
+                                 p.first_us, p.best_us));
+    }
+    d["table"] = rows;
+    return d;
+  }
+
+ private:
+  std::mutex mu_;
+  std::map<int, hipblasLtHandle_t> handles_;
+  std::map<int, at::Tensor> workspaces_;
+  std::map<Key, Plan> plans_;
+  Stats stats_;
+
+  hipblasLtHandle_t handle_for(int device) {
+    auto it = handles_.find(device);
+    if (it != handles_.end()) return it->second;
+    hipblasLtHandle_t h;
+    PDA_LT_CHECK(hipblasLtCreate(&h));
+    handles_[device] = h;
+    return h;
+  }
+
+  void* workspace_for(int device) {
+    auto it = workspaces_.find(device);
+    if (it == workspaces_.end()) {
+      auto opts = at::TensorOptions().dtype(at::kByte).device(at::kCUDA, device);
+      it = workspaces_.emplace(device, at::empty({(int64_t)workspace_limit}, opts)).first;
+    }
+    return it->second.data_ptr();
+  }
+
+  // Column-major view of a row-major [rows, cols] matrix with row stride ld: cols x rows, ld.
+  static hipblasLtMatrixLayout_t layout(int64_t rows, int64_t cols, int64_t ld) {
+    hipblasLtMatrixLayout_t l;
+    PDA_LT_CHECK(hipblasLtMatrixLayoutCreate(&l, HIP_R_16BF, (uint64_t)cols, (uint64_t)rows, ld));
+    return l;
+  }
+
+  Plan make_plan(hipblasLtHandle_t handle, const Key& key) {
+    Plan p;
+    PDA_LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    // out^T (n x m) = op(b) . op(a): b supplies the library's "A", a its "B".
+    const hipblasOperation_t op_first = key.trans_b ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    const hipblasOperation_t op_second = key.trans_a ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first)));
+    PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second)));
+    hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_DEFAULT;
+    if (key.epilogue == kBias) ep = HIPBLASLT_EPILOGUE_BIAS;
+    PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep)));
+    if (key.epilogue == kBias) {
+      const int32_t bias_type = HIP_R_16BF;
+      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type,
+                                                   sizeof(bias_type)));
+    }
+    // Row-major operand shapes as stored.
+    const int64_t a_rows = key.trans_a ? key.k : key.m, a_cols = key.trans_a ? key.m : key.k;
+    const int64_t b_rows = key.trans_b ? key.n : key.k, b_cols = key.trans_b ? key.k : key.n;
+    p.la = layout(b_rows, b_cols, key.ldb);  // library "A" = our b
+    p.lb = layout(a_rows, a_cols, key.lda);  // library "B" = our a
+    p.lo = layout(key.m, key.n, key.ldo);
+    p.candidates = -1;  // algorithm not chosen yet (chosen by timing with the caller's operands)
+    ++stats_.plans;
+    (void)handle;
+    return p;
+  }
+
+  static void set_pointers(Plan& p, int epilogue, const void* bias) {
+    if (epilogue == kBias)
+      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  }
+
+  void launch(hipblasLtHandle_t handle, const Plan& p, const hipblasLtMatmulAlgo_t& algo, const at::Tensor& a,
+              const at::Tensor& b, at::Tensor& out, void* ws, hipStream_t stream) {
+    const float alpha = 1.f, beta = 0.f;
+    PDA_LT_CHECK(hipblasLtMatmul(handle, p.desc, &alpha, b.data_ptr(), p.la, a.data_ptr(), p.lb, &beta,
+                                 out.data_ptr(), p.lo, out.data_ptr(), p.lo, &algo, ws, workspace_limit, stream));
+  }
+
+  void choose(hipblasLtHandle_t handle, Plan& p, const at::Tensor& a, const at::Tensor& b, at::Tensor& out, void* ws,
+              hipStream_t stream) {
+    hipblasLtMatmulPreference_t pref;
+    PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+    PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
+                                                       &workspace_limit, sizeof(workspace_limit)));
+    const int want = tuning ? std::max(1, max_candidates) : 1;
+    std::vector<hipblasLtMatmulHeuristicResult_t> found(want);
+    int returned = 0;
+    PDA_LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lo, p.lo, pref, want, found.data(),
+                                                 &returned));
+    hipblasLtMatmulPreferenceDestroy(pref);
+    TORCH_CHECK(returned > 0, "hipBLASLt has no algorithm for this GEMM (m=", out.size(0), " n=", out.size(1), ")");
+    found.resize(returned);
+    p.candidates = returned;
+    p.chosen = 0;
+    p.algo = found[0].algo;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capturing);
+    if (!tuning || returned == 1 || capturing != hipStreamCaptureStatusNone) return;
+
+    hipEvent_t e0, e1;
+    PDA_HIP_CHECK(hipEventCreate(&e0));
+    PDA_HIP_CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int i = 0; i < returned; ++i) {
+      if (found[i].state != HIPBLAS_STATUS_SUCCESS || found[i].workspaceSize > workspace_limit) continue;
+      const float alpha = 1.f, beta = 0.f;
+      // warm-up run doubles as the validity check of the candidate
+      hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, b.data_ptr(), p.la, a.data_ptr(), p.lb, &beta,
+                                           out.data_ptr(), p.lo, out.data_ptr(), p.lo, &found[i].algo, ws,
+                                           workspace_limit, stream);
+      if (st != HIPBLAS_STATUS_SUCCESS) continue;
+      PDA_HIP_CHECK(hipEventRecord(e0, stream));
+      for (int r = 0; r < timed_runs; ++r) launch(handle, p, found[i].algo, a, b, out, ws, stream);
+      PDA_HIP_CHECK(hipEventRecord(e1, stream));
+      PDA_HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      PDA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      const float us = ms * 1e3f / timed_runs;
+      if (i == 0) p.first_us = us;
+      if (us < best) {
+        best = us;
+        p.chosen = i;
+        p.algo = found[i].algo;
+      }
+    }
+    p.best_us = best;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ++stats_.tuned;
+  }
+};
+
+void check_matrix(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.defined() && t.is_cuda(), name, " must be a GPU tensor");
+  TORCH_CHECK(t.scalar_type() == at::kBFloat16, name, " must be bfloat16");
+  TORCH_CHECK(t.dim() == 2 && t.stride(1) == 1 && t.stride(0) >= t.size(1), name,
+              " must be a row-major matrix with unit column stride");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0 && t.stride(0) % 8 == 0, name,
+              " must be 16-byte aligned with a row stride that is a multiple of 8");
+}
+
+// out[M,N] = epilogue(op(a) . op(b)); op(x) = x^T when trans_x. Returns out.
+at::Tensor lt_matmul(const at::Tensor& a, bool trans_a, const at::Tensor& b, bool trans_b,
+                     const std::optional<at::Tensor>& out_opt, const std::string& epilogue,
+                     const std::optional<at::Tensor>& bias) {
+  check_matrix(a, "a");
+  check_matrix(b, "b");
+  const c10::DeviceGuard guard(a.device());
+  const int64_t m = trans_a ? a.size(1) : a.size(0);
+  const int64_t k = trans_a ? a.size(0) : a.size(1);
+  const int64_t kb = trans_b ? b.size(1) : b.size(0);
+  const int64_t n = trans_b ? b.size(0) : b.size(1);
+  TORCH_CHECK(k == kb, "lt_matmul: inner dimensions differ (", k, " vs ", kb, ")");
+  TORCH_CHECK(m > 0 && n > 0 && k > 0, "lt_matmul: empty problem");
+  at::Tensor out = out_opt.has_value() ? *out_opt : at::empty({m, n}, a.options());
+  check_matrix(out, "out");
+  TORCH_CHECK(out.size(0) == m && out.size(1) == n, "lt_matmul: out has the wrong shape");
+
+  int ep = kNone;
+  const void* bias_ptr = nullptr;
+  if (epilogue == "bias") ep = kBias;
+  else TORCH_CHECK(epilogue == "none", "lt_matmul: unknown epilogue '", epilogue, "'");
+  if (ep == kBias) {
+    TORCH_CHECK(bias.has_value() && bias->is_cuda() && bias->scalar_type() == at::kBFloat16 &&
+                    bias->is_contiguous() && bias->numel() == n,
+                "lt_matmul: bias must be a contiguous bf16 GPU vector of length ", n);
+    bias_ptr = bias->data_ptr();
+  }
+  Planner::get().run(a, trans_a, b, trans_b, out, ep, bias_ptr);
+  return out;
+}
+
+}  // namespace
+
+void bind_gemm(py::module_& m) {
+  m.def("lt_matmul", &lt_matmul, py::arg("a"), py::arg("trans_a"), py::arg("b"), py::arg("trans_b"),
+        py::arg("out") = py::none(), py::arg("epilogue") = "none", py::arg("bias") = py::none(),
+        "Row-major bf16 GEMM with an optional fused bias add (epilogue 'none' | 'bias'); the algorithm is "
+        "picked by timing the library's candidates on first use of each problem.");
+  m.def("gemm_planner_configure", [](bool tuning, int max_candidates, int timed_runs) {
+    auto& p = Planner::get();
+    p.tuning = tuning;
+    p.max_candidates = max_candidates;
+    p.timed_runs = timed_runs;
+  }, py::arg("tuning") = true, py::arg("max_candidates") = 24, py::arg("timed_runs") = 3);
+  m.def("gemm_planner_stats", []() { return Planner::get().stats(); });
+}
+
+}  // namespace pda

@@ -1,15 +1,21 @@
-"""Linear layer with a native weight-gradient kernel.
+"""Linear layer: planned library GEMMs for forward / input gradient, native kernel for the
+weight gradient.
 
-Forward and input-gradient GEMMs go to hipBLASLt through ``F.linear`` / ``torch.mm`` (their
-contraction dimension is contiguous in both operands and the library handles them at
-~1.2 PFLOP/s). The weight gradient ``dW = dY^T . X`` contracts over the token dimension —
-the row index of both operands — and produces a small output; there the library reaches
-only 0.4-0.85 PFLOP/s on GPT-2 shapes, so it is done by ``csrc/kernels/gemm_wgrad.hip``
-(split-K over tokens, transposed LDS operand reads), which also returns the bias gradient
-as a by-product instead of a separate reduction pass over ``dY``.
+* Forward ``y = x W^T + b`` and input gradient ``dx = dy W`` contract over a dimension that is
+  contiguous in both operands — plain library GEMMs. They go through the C++ GEMM planner
+  (``csrc/runtime/gemm_planner.cpp``): hipBLASLt with the bias add fused into the epilogue
+  and the algorithm picked by timing the library's candidates the first time each shape is
+  seen (5-25 % faster than the default heuristic on the tall shapes of training).
+* The weight gradient ``dW = dY^T . X`` contracts over the token dimension — the row index of
+  both operands — and produces a small output; there the library reaches only
+  0.4-0.85 PFLOP/s on GPT-2 shapes, so it is done by ``csrc/kernels/gemm_wgrad.hip``
+  (split-K over tokens, transposed LDS operand reads), which also returns the bias gradient
+  as a by-product instead of a separate reduction pass over ``dY``.
 
-Falls back to the library for shapes the kernel does not cover (non-bf16, dimensions not
-multiples of 256, e.g. the V = 50257 LM head) and on the CPU.
+Shapes the native paths do not cover (non-bf16, dimensions not multiples of 256 for the
+weight gradient, e.g. d = 1600) and CPU tensors use ``torch`` matmuls.
+``PDA_NO_NATIVE_WGRAD=1`` / ``PDA_NO_GEMM_PLANNER=1`` switch the two native paths off
+(A/B measurements).
 """
 from __future__ import annotations
 
@@ -29,12 +35,38 @@ def _native_wgrad_ok(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
     return _ext.require().wgrad_supported(dy2.shape[0], dy2.shape[1], x2.shape[1])
 
 
+def _planner_ok(*mats: torch.Tensor) -> bool:
+    if os.environ.get("PDA_NO_GEMM_PLANNER") == "1":
+        return False
+    for m in mats:
+        if not (m.is_cuda and m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1
+                and m.stride(0) % 8 == 0 and m.stride(0) >= m.shape[1] and m.data_ptr() % 16 == 0
+                and m.numel() > 0):
+            return False
+    return True
+
+
+def planned_mm(a: torch.Tensor, b: torch.Tensor, *, trans_b: bool = False, bias=None, out=None) -> torch.Tensor:
+    """``a @ b`` (or ``a @ b.T`` with ``trans_b``) ``+ bias`` for 2-D row-major bf16 GPU matrices
+    through the GEMM planner; plain ``torch`` otherwise."""
+    mats = (a, b) if out is None else (a, b, out)
+    if _planner_ok(*mats) and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous())):
+        return _ext.require().lt_matmul(a, False, b, trans_b, out, "none" if bias is None else "bias", bias)
+    bm = b.t() if trans_b else b
+    if bias is not None:
+        res = torch.addmm(bias, a, bm)
+        return res if out is None else out.copy_(res)
+    return torch.mm(a, bm, out=out) if out is not None else torch.mm(a, bm)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1])
+        y = planned_mm(x2, weight, trans_b=True, bias=bias)
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -43,7 +75,7 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dy2, weight).view(x.shape)
+            dx = planned_mm(dy2, weight).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if need_w and _native_wgrad_ok(dy2, x2):
             if not dy2.is_contiguous():

@@ -173,9 +173,12 @@ def test_fused_adamw_matches_torch(dtype):
             p.grad = g.to(dtype)
             if dtype == torch.bfloat16:
                 r.grad = p.grad.float()
-        opt.step(zero_grad=(step % 2 == 0))
+        # even steps clear the gradients: dropped on step 0, zeroed inside the kernel on 2 and 4
+        opt.step(zero_grad=(step % 2 == 0), set_to_none=(step == 0))
         ref.step()
-        if step % 2 == 0:
+        if step == 0:
+            assert all(p.grad is None for p in params)
+        elif step % 2 == 0:
             assert all(float(p.grad.abs().max()) == 0.0 for p in params)
     for p, r in zip(params, ref_params):
         master = opt.state[p].get("master", p.data)
