@@ -276,7 +276,8 @@ void accumulate_bf16_into_f32(const at::Tensor& src, at::Tensor dst, double scal
 }
 
 // -------------------------------------------------------------- attention --
-std::vector<at::Tensor> attention_forward(const at::Tensor& qkv, int64_t num_heads, double softmax_scale) {
+std::vector<at::Tensor> attention_forward(const at::Tensor& qkv, int64_t num_heads, double softmax_scale,
+                                          double dropout_p, uint64_t seed) {
   check_gpu(qkv, "qkv");
   TORCH_CHECK(qkv.scalar_type() == at::kBFloat16, "attention: bf16 only");
   TORCH_CHECK(qkv.dim() == 3, "attention: qkv must be [B, T, 3*H*D]");
@@ -285,17 +286,19 @@ std::vector<at::Tensor> attention_forward(const at::Tensor& qkv, int64_t num_hea
   const int64_t D = three_hd / (3 * num_heads);
   TORCH_CHECK(D == 64 || D == 128, "attention: head_dim must be 64 or 128, got ", D);
   TORCH_CHECK(T >= 1 && B >= 1, "attention: empty input");
+  TORCH_CHECK(dropout_p >= 0.0 && dropout_p < 1.0, "attention: dropout_p must be in [0, 1)");
   const c10::DeviceGuard guard(qkv.device());
   at::Tensor out = at::empty({B, T, num_heads * D}, qkv.options());
   at::Tensor lse = at::empty({B, num_heads, T}, qkv.options().dtype(at::kFloat));
   pda::attention_forward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), (int)B, (int)T,
-                         (int)num_heads, (int)D, (float)softmax_scale, current_stream());
+                         (int)num_heads, (int)D, (float)softmax_scale, (float)dropout_p, seed, current_stream());
   check_launch("attention_forward");
   return {out, lse};
 }
 
 at::Tensor attention_backward(const at::Tensor& qkv, const at::Tensor& out, const at::Tensor& dout,
-                              const at::Tensor& lse, int64_t num_heads, double softmax_scale) {
+                              const at::Tensor& lse, int64_t num_heads, double softmax_scale,
+                              double dropout_p, uint64_t seed) {
   check_gpu(qkv, "qkv");
   check_gpu(out, "out");
   check_gpu(dout, "dout");
@@ -314,9 +317,21 @@ at::Tensor attention_backward(const at::Tensor& qkv, const at::Tensor& out, cons
   at::Tensor delta = at::empty_like(lse);
   pda::attention_backward(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(),
                           delta.data_ptr<float>(), dqkv.data_ptr(), (int)B, (int)T, (int)num_heads,
-                          (int)D, (float)softmax_scale, current_stream());
+                          (int)D, (float)softmax_scale, (float)dropout_p, seed, current_stream());
   check_launch("attention_backward");
   return dqkv;
+}
+
+// keep[B, H, T, T] (bool): the attention-dropout mask the kernels apply for (dropout_p, seed).
+at::Tensor attention_dropout_mask(int64_t B, int64_t H, int64_t T, double dropout_p, uint64_t seed,
+                                  const at::Device& device) {
+  TORCH_CHECK(device.is_cuda(), "attention_dropout_mask: GPU device expected");
+  const c10::DeviceGuard guard(device);
+  at::Tensor keep = at::empty({B, H, T, T}, at::TensorOptions().dtype(at::kByte).device(device));
+  pda::attention_dropout_mask(keep.data_ptr<uint8_t>(), (int)B, (int)T, (int)H, (float)dropout_p, seed,
+                              current_stream());
+  check_launch("attention_dropout_mask");
+  return keep.to(at::kBool);
 }
 
 // ---------------------------------------------------------------- weight grad --
@@ -375,7 +390,10 @@ void bind_ops(py::module_& m) {
         py::arg("zero_grad"));
   m.def("accumulate_bf16_into_f32", &accumulate_bf16_into_f32);
   m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("num_heads"),
-        py::arg("softmax_scale"));
+        py::arg("softmax_scale"), py::arg("dropout_p") = 0.0, py::arg("seed") = 0);
   m.def("attention_backward", &attention_backward, py::arg("qkv"), py::arg("out"), py::arg("dout"),
-        py::arg("lse"), py::arg("num_heads"), py::arg("softmax_scale"));
+        py::arg("lse"), py::arg("num_heads"), py::arg("softmax_scale"), py::arg("dropout_p") = 0.0,
+        py::arg("seed") = 0);
+  m.def("attention_dropout_mask", &attention_dropout_mask, py::arg("B"), py::arg("H"), py::arg("T"),
+        py::arg("dropout_p"), py::arg("seed"), py::arg("device"));
 }

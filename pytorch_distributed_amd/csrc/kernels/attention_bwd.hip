@@ -29,6 +29,8 @@
 #include <type_traits>
 
 namespace pda {
+using attn::DropoutParams;
+using attn::make_dropout_params;
 namespace {
 
 using namespace attn;
@@ -43,11 +45,11 @@ constexpr int kBN = 64;   // rows per streamed tile (keys in dq, queries in dkv)
 // registers) it parks them in AGPRs and moves every S / dP / dS element across with
 // v_accvgpr_read/write — 130-160 extra VALU instructions per 16 MFMAs, which made these
 // kernels VALU-bound at 20 % matrix-pipe utilisation.
-template <int D>
+template <int D, bool kDrop>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 2 : 1))) void attn_bwd_dq_kernel(
     const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ out,
     const bf16_raw* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta_out,
-    bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale) {
+    bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale, DropoutParams drop) {
   constexpr int kKSteps = D / 16;
   constexpr int kDBlocks = D / 32;
   constexpr int kTileBytes = kBN * D * 2;
@@ -161,6 +163,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
             s_acc[kb][i + 1] = ds[1];
           }
       };
+      if (kDrop) {
+        // dP of a dropped probability is zero and of a kept one is scaled: rebuild dP from the
+        // chain's (dP - delta) before the softmax gradient. The mask is the forward's.
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int kbase = key0 + kb * 32 + 8 * g + 4 * h;
+            const u32x4 blk = dropout_block(drop, bh, q_row, kbase);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool keep = dropout_keep(drop, blk, q_row, kbase + e);
+              const float dp_true = dp_acc[kb][4 * g + e] + delta;
+              dp_acc[kb][4 * g + e] = (keep ? dp_true * drop.keep_scale : 0.f) - delta;
+            }
+          }
+      }
       if (__builtin_expect(diag, 0)) softmax_grad(std::true_type{});
       else softmax_grad(std::false_type{});
 #pragma unroll
@@ -198,10 +217,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
 }
 
 // ========================================================================= dK / dV
-template <int D>
+template <int D, bool kDrop>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 2 : 1))) void attn_bwd_dkv_kernel(
     const bf16_raw* __restrict__ qkv, const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale) {
+    const float* __restrict__ delta, bf16_raw* __restrict__ dqkv, int B, int T, int H, float scale,
+    DropoutParams drop) {
   constexpr int kKSteps = D / 16;
   constexpr int kDBlocks = D / 32;
   constexpr int kTileBytes = kBN * D * 2;
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         if (qs + 31 < key0 || qs >= T) continue;  // wave-uniform: entirely above the diagonal / past the end
         // Row constants of the 16 accumulator rows this lane holds (queries qs + acc_row(i, h)).
         f32x16 s_acc, dp_acc;
+        float neg_delta[kDrop ? 16 : 1];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           // chains end as S - LSE/scale (so exp2(c * acc) = P) and dP - delta
@@ -298,6 +319,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
           for (int e = 0; e < 4; ++e) {
             s_acc[4 * g + e] = a[e];
             dp_acc[4 * g + e] = d[e];
+            if (kDrop) neg_delta[4 * g + e] = d[e];
           }
         }
 #pragma unroll
@@ -316,6 +338,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         // diagonal or past the end of the sequence evaluate the mask (separate code paths:
         // folded into one, the per-element compares ran on every tile).
         const f32x2 c2 = {c, c};
+        // Dropout: the forward multiplied V by keep * P / (1 - p). dV takes that dropped P; dS is
+        // the undropped P times (keep * dP / (1 - p) - delta). keep_mask bit i = element i kept.
+        uint32_t keep_mask = 0xffffu;
+        if (kDrop) {
+          keep_mask = 0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int qbase = qs + 8 * g + 4 * h;  // this lane's queries qbase .. qbase + 3 (one key)
+            const u32x4 blk = dropout_block(drop, bh, qbase, key);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (dropout_keep(drop, blk, qbase + e, key)) keep_mask |= 1u << (4 * g + e);
+          }
+        }
         auto softmax_grad = [&](auto masked) {
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
@@ -326,11 +362,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
               if (q < key || q >= T) p[0] = 0.f;
               if (q + 1 < key || q + 1 >= T) p[1] = 0.f;
             }
-            const f32x2 ds = p * f32x2{dp_acc[i], dp_acc[i + 1]};
-            s_acc[i] = p[0];
-            s_acc[i + 1] = p[1];
-            dp_acc[i] = ds[0];
-            dp_acc[i + 1] = ds[1];
+            if (kDrop) {
+              const bool k0 = (keep_mask >> i) & 1, k1 = (keep_mask >> (i + 1)) & 1;
+              const float dp0 = (k0 ? (dp_acc[i] - neg_delta[i]) * drop.keep_scale : 0.f) + neg_delta[i];
+              const float dp1 = (k1 ? (dp_acc[i + 1] - neg_delta[i + 1]) * drop.keep_scale : 0.f) + neg_delta[i + 1];
+              dp_acc[i] = p[0] * dp0;
+              dp_acc[i + 1] = p[1] * dp1;
+              s_acc[i] = k0 ? p[0] * drop.keep_scale : 0.f;
+              s_acc[i + 1] = k1 ? p[1] * drop.keep_scale : 0.f;
+            } else {
+              const f32x2 ds = p * f32x2{dp_acc[i], dp_acc[i + 1]};
+              s_acc[i] = p[0];
+              s_acc[i + 1] = p[1];
+              dp_acc[i] = ds[0];
+              dp_acc[i + 1] = ds[1];
+            }
           }
         };
         if (__builtin_expect(diag || tail, 0)) softmax_grad(std::true_type{});
@@ -383,24 +429,42 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
 
 void attention_backward(const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int B, int T, int H, int D, float softmax_scale,
-                        hipStream_t stream) {
+                        float dropout_p, uint64_t seed, hipStream_t stream) {
   const int n_bt = (T + kBM - 1) / kBM;
   dim3 grid((unsigned)(n_bt * B * H)), block(kThreads);
+  const DropoutParams drop = make_dropout_params(dropout_p, seed);
+  const size_t lds = size_t(2) * 2 * kBN * D * 2;
+  auto launch = [&](auto dq_kern, auto dkv_kern) {
+    hipLaunchKernelGGL(dq_kern, grid, block, lds, stream, (const bf16_raw*)qkv, (const bf16_raw*)out,
+                       (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale, drop);
+    hipLaunchKernelGGL(dkv_kern, grid, block, lds + 1024, stream, (const bf16_raw*)qkv, (const bf16_raw*)dout, lse,
+                       delta, (bf16_raw*)dqkv, B, T, H, softmax_scale, drop);
+  };
   if (D == 64) {
-    constexpr size_t lds = 2 * 2 * kBN * 64 * 2;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, lds, stream, (const bf16_raw*)qkv,
-                       (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H,
-                       softmax_scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, lds + 1024, stream, (const bf16_raw*)qkv,
-                       (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale);
+    if (drop.threshold) launch(attn_bwd_dq_kernel<64, true>, attn_bwd_dkv_kernel<64, true>);
+    else launch(attn_bwd_dq_kernel<64, false>, attn_bwd_dkv_kernel<64, false>);
   } else {
-    constexpr size_t lds = 2 * 2 * kBN * 128 * 2;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, block, lds, stream, (const bf16_raw*)qkv,
-                       (const bf16_raw*)out, (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H,
-                       softmax_scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, block, lds + 1024, stream, (const bf16_raw*)qkv,
-                       (const bf16_raw*)dout, lse, delta, (bf16_raw*)dqkv, B, T, H, softmax_scale);
+    if (drop.threshold) launch(attn_bwd_dq_kernel<128, true>, attn_bwd_dkv_kernel<128, true>);
+    else launch(attn_bwd_dq_kernel<128, false>, attn_bwd_dkv_kernel<128, false>);
   }
+}
+
+// keep[b][h][q][k] = 1 where the dropout mask keeps probability (q, k): the mask the kernels
+// apply, materialised for tests.
+namespace {
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, int BH, int T, DropoutParams drop) {
+  const int64_t n = int64_t(BH) * T * T;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    const int k = int(i % T), q = int((i / T) % T), bh = int(i / (int64_t(T) * T));
+    const u32x4 blk = attn::dropout_block(drop, bh, q, k);
+    keep[i] = attn::dropout_keep(drop, blk, q, k) ? 1 : 0;
+  }
+}
+}  // namespace
+
+void attention_dropout_mask(uint8_t* keep, int B, int T, int H, float dropout_p, uint64_t seed, hipStream_t stream) {
+  const DropoutParams drop = make_dropout_params(dropout_p, seed);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(1024), dim3(256), 0, stream, keep, B * H, T, drop);
 }
 
 }  // namespace pda

@@ -26,6 +26,8 @@
 #include "pda_kernels.h"
 
 namespace pda {
+using attn::DropoutParams;
+using attn::make_dropout_params;
 namespace {
 
 using namespace attn;
@@ -39,11 +41,10 @@ constexpr int kBN = 64;   // keys per tile
 // accumulators in ordinary VGPRs (with the launch-bounds default of 512 the compiler parks
 // them in AGPRs and copies every score across for the softmax) and lets three workgroups
 // share a CU.
-template <int D>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 1))) void attn_fwd_kernel(const bf16_raw* __restrict__ qkv,
-                                                            bf16_raw* __restrict__ out,
-                                                            float* __restrict__ lse_out, int B, int T,
-                                                            int H, float scale) {
+template <int D, bool kDrop>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? (kDrop ? 2 : 3) : 1))) void attn_fwd_kernel(
+    const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, float* __restrict__ lse_out, int B, int T, int H,
+    float scale, DropoutParams drop) {
   constexpr int kKSteps = D / 16;   // k-steps of the S^T product
   constexpr int kDBlocks = D / 32;  // 32-row blocks of O^T
   constexpr int kTileBytes = kBN * D * 2;
@@ -166,6 +167,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
             o_acc[db][i + 1] = o[1];
           }
       }
+      // ---- attention dropout: the row sum above is of the undropped probabilities ----------
+      if (kDrop) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int kbase = key0 + kb * 32 + 8 * g + 4 * h;  // this lane's keys kbase .. kbase + 3
+            const u32x4 blk = dropout_block(drop, bh, q_row, kbase);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool keep = dropout_keep(drop, blk, q_row, kbase + e);
+              s_acc[kb][4 * g + e] = keep ? s_acc[kb][4 * g + e] * drop.keep_scale : 0.f;
+            }
+          }
+      }
       // ---- O^T += V^T . P^T ---------------------------------------------------
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -211,15 +227,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
 }  // namespace
 
 void attention_forward(const void* qkv, void* out, float* lse, int B, int T, int H, int D,
-                       float softmax_scale, hipStream_t stream) {
+                       float softmax_scale, float dropout_p, uint64_t seed, hipStream_t stream) {
   const int n_qt = (T + kBM - 1) / kBM;
   dim3 grid((unsigned)(n_qt * B * H)), block(kThreads);
+  const DropoutParams drop = make_dropout_params(dropout_p, seed);
+  const size_t lds = size_t(2) * 2 * kBN * D * 2;
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, (const bf16_raw*)qkv, (bf16_raw*)out, lse, B, T, H,
+                       softmax_scale, drop);
+  };
   if (D == 64) {
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 2 * 2 * kBN * 64 * 2, stream,
-                       (const bf16_raw*)qkv, (bf16_raw*)out, lse, B, T, H, softmax_scale);
+    if (drop.threshold) launch(attn_fwd_kernel<64, true>);
+    else launch(attn_fwd_kernel<64, false>);
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 2 * 2 * kBN * 128 * 2, stream,
-                       (const bf16_raw*)qkv, (bf16_raw*)out, lse, B, T, H, softmax_scale);
+    if (drop.threshold) launch(attn_fwd_kernel<128, true>);
+    else launch(attn_fwd_kernel<128, false>);
   }
 }
 

@@ -86,12 +86,16 @@ void cross_entropy_fwd_bwd(DType dtype, void* logits, const int64_t* targets, fl
 // ----------------------------------------------------------------- Attention --
 // Causal self-attention over a packed QKV activation [B, T, 3, H, D] (bf16),
 // D in {64, 128}. out is [B, T, H, D] bf16, lse is [B, H, T] fp32 (natural log).
+// dropout_p > 0 drops attention probabilities with a counter-based (Philox) mask derived from
+// `seed`; the backward must be given the same dropout_p and seed.
 void attention_forward(const void* qkv, void* out, float* lse, int B, int T, int H, int D,
-                       float softmax_scale, hipStream_t stream);
+                       float softmax_scale, float dropout_p, uint64_t seed, hipStream_t stream);
 // dqkv has the layout of qkv. delta is an fp32 [B, H, T] workspace.
 void attention_backward(const void* qkv, const void* out, const void* dout, const float* lse,
                         float* delta, void* dqkv, int B, int T, int H, int D, float softmax_scale,
-                        hipStream_t stream);
+                        float dropout_p, uint64_t seed, hipStream_t stream);
+// keep[B*H][T][T] (bytes): 1 where the dropout mask of (dropout_p, seed) keeps the probability.
+void attention_dropout_mask(uint8_t* keep, int B, int T, int H, float dropout_p, uint64_t seed, hipStream_t stream);
 
 // ------------------------------------------------------------- Weight gradient --
 // C[I, J] = A[M, I]^T . B[M, J] (bf16 operands, row strides lda / ldb in elements) with the

@@ -262,3 +262,48 @@ def test_attention_backward_deterministic():
         ops.causal_attention(a, H).backward(dout)
         grads.append(a.grad.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("B,T,H,D,p", [(2, 512, 3, 64, 0.1), (1, 333, 2, 64, 0.25), (1, 256, 2, 128, 0.1)])
+def test_attention_dropout_matches_reference_with_same_mask(B, T, H, D, p):
+    """Forward and backward with in-kernel dropout against the eager op sequence using the mask the
+    kernels generate (materialised by attention_dropout_mask from the same seed)."""
+    ext = _ext_loaded()
+    from pytorch_distributed_amd.ops.attention import dropout_quantised
+
+    torch.manual_seed(10)
+    seed = 123456789012345
+    qkv = torch.randn(B, T, 3 * H * D, device=DEV, dtype=torch.bfloat16)
+    dout = torch.randn(B, T, H * D, device=DEV, dtype=torch.bfloat16)
+    keep = ext.attention_dropout_mask(B, H, T, p, seed, torch.device(DEV))
+    p_q, keep_scale = dropout_quantised(p)
+    causal = torch.ones(T, T, dtype=torch.bool, device=DEV).tril()
+    frac_dropped = 1.0 - keep[:, :, causal].float().mean().item()
+    assert abs(frac_dropped - p_q) < 0.01, (frac_dropped, p_q)
+
+    a = qkv.clone().requires_grad_(True)
+    out = ops.causal_attention(a, H, dropout_p=p, training=True, seed=seed)
+    out.backward(dout)
+    r = qkv.float().requires_grad_(True)
+    ref = ops.attention_reference(r, H, keep_mask=keep, keep_scale=keep_scale)
+    ref.backward(dout.float())
+    assert rel_err(out, ref) < 1.5e-2, rel_err(out, ref)
+    g, gr = a.grad.view(B, T, 3, H * D), r.grad.view(B, T, 3, H * D)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        e = rel_err(g[:, :, i], gr[:, :, i])
+        assert e < 2.5e-2, (name, e)
+    # a different seed gives a different mask; eval mode ignores dropout
+    other = ops.causal_attention(qkv, H, dropout_p=p, training=True, seed=seed + 1)
+    assert not torch.equal(other, out.detach())
+    assert torch.equal(ops.causal_attention(qkv, H, dropout_p=p, training=False), ops.causal_attention(qkv, H))
+
+
+def test_attention_dropout_follows_torch_seed():
+    _ext_loaded()
+    qkv = torch.randn(1, 128, 3 * 2 * 64, device=DEV, dtype=torch.bfloat16)
+    torch.manual_seed(3)
+    a = ops.causal_attention(qkv, 2, dropout_p=0.2, training=True)
+    b = ops.causal_attention(qkv, 2, dropout_p=0.2, training=True)
+    torch.manual_seed(3)
+    c = ops.causal_attention(qkv, 2, dropout_p=0.2, training=True)
+    assert torch.equal(a, c) and not torch.equal(a, b)
