@@ -97,13 +97,17 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
 // instruction. The LDS destination is "wave base + lane * 16" (hardware rule), so lane p lands
 // on (row + p/32, slot p % 32); it therefore FETCHES the chunk that belongs in that slot:
 // slot ^ swizzle(row).
-__device__ __forceinline__ void stage_half(const bf16_raw* base, int64_t ld, int row0, int col0, char* tile,
-                                           int half, int wave, int lane) {
+// Columns past `cols` (edge tiles of a dimension that is not a multiple of 256) are clamped to the
+// last 16-byte chunk of the row: the duplicate data lands in tile columns whose results are
+// never stored.
+__device__ __forceinline__ void stage_half(const bf16_raw* base, int64_t ld, int row0, int col0, int cols,
+                                           char* tile, int half, int wave, int lane) {
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
   const int row = 16 * half + 2 * wave + (lane >> 5);
   const int chunk = (lane & 31) ^ ((row & 3) << 2);
-  const bf16_raw* src = base + int64_t(row0 + row) * ld + col0 + chunk * 8;
+  const int col = min(col0 + chunk * 8, cols - 8);
+  const bf16_raw* src = base + int64_t(row0 + row) * ld + col;
   char* dst = tile + (16 * half + 2 * wave) * kRowBytes;  // wave-uniform
   __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
 }
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
   const int h = lane >> 5, r = lane & 31;
 
   // ---- task mapping -------------------------------------------------------------------
-  const int tiles_j = J / kTile, tiles_i = I / kTile;
+  const int tiles_j = (J + kTile - 1) / kTile, tiles_i = (I + kTile - 1) / kTile;  // edge tiles are partial
   const int n_tiles = tiles_i * tiles_j;
   const int n_tasks = n_tiles * S;
   // Workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous task range.
@@ -165,8 +169,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
     const int row0 = (step_lo + t) * kBM;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      stage_half(A, lda, row0, ti * kTile, slot, half, wave, lane);
-      stage_half(B, ldb, row0, tj * kTile, slot + kTileBytes, half, wave, lane);
+      stage_half(A, lda, row0, ti * kTile, I, slot, half, wave, lane);
+      stage_half(B, ldb, row0, tj * kTile, J, slot + kTileBytes, half, wave, lane);
     }
   };
 #pragma unroll
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
       for (int e = 0; e < 16; ++e) {
         const int i = 32 * (4 * wi + a) + acc_row(e, h);
         const int j = 32 * (2 * wj + b) + r;
-        cp[int64_t(i) * J + j] = acc[a][b][e];
+        if (ti * kTile + i < I && tj * kTile + j < J) cp[int64_t(i) * J + j] = acc[a][b][e];
       }
 
   if (do_bias) {  // fold the 16 threads that share a chunk (same tid & 31) through LDS
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
       float s = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) s += red[g * kTile + tid];
-      bias_partial[int64_t(slice) * I + ti * kTile + tid] = s;
+      if (ti * kTile + tid < I) bias_partial[int64_t(slice) * I + ti * kTile + tid] = s;
     }
   }
 }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }  // namespace
 
 int wgrad_pick_slices(int M, int I, int J) {
-  const int n_tiles = (I / kTile) * (J / kTile);
+  const int n_tiles = ((I + kTile - 1) / kTile) * ((J + kTile - 1) / kTile);
   const int steps = M / kBM;
   int best = 1;
   double best_score = -1.0;
@@ -346,12 +350,13 @@ int wgrad_pick_slices(int M, int I, int J) {
 }
 
 bool wgrad_supported(int M, int I, int J) {
-  return M >= kBM && M % kBM == 0 && I % kTile == 0 && J % kTile == 0 && I > 0 && J > 0;
+  // 16-byte chunks must not straddle the end of a row; partial edge tiles are handled in-kernel.
+  return M >= kBM && M % kBM == 0 && I % 8 == 0 && J % 8 == 0 && I >= 8 && J >= 8;
 }
 
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream) {
-  const int n_tasks = (I / kTile) * (J / kTile) * S;
+  const int n_tasks = ((I + kTile - 1) / kTile) * ((J + kTile - 1) / kTile) * S;
   static int mode = -1;
   if (mode < 0) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);

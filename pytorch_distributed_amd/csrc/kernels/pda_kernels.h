@@ -100,8 +100,9 @@ void attention_dropout_mask(uint8_t* keep, int B, int T, int H, float dropout_p,
 // ------------------------------------------------------------- Weight gradient --
 // C[I, J] = A[M, I]^T . B[M, J] (bf16 operands, row strides lda / ldb in elements) with the
 // contraction M split over S slices: fp32 partials [S][I][J] (+ optional column sums of A,
-// [S][I], the bias gradient), folded by wgrad_reduce. Needs M % 64 == 0, I % 256 == 0,
-// J % 256 == 0 (wgrad_supported); wgrad_pick_slices chooses S to fill the 256 CUs.
+// [S][I], the bias gradient), folded by wgrad_reduce. Needs M % 32 == 0, I % 8 == 0, J % 8 == 0
+// (wgrad_supported; output tiles are 256 x 256, partial at the edges); wgrad_pick_slices
+// chooses S to fill the 256 CUs.
 bool wgrad_supported(int M, int I, int J);
 int wgrad_pick_slices(int M, int I, int J);
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,

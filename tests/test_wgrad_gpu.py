@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,I,J", [(8192, 1280, 1280), (4096, 3840, 1280), (8192, 256, 5120), (64, 256, 256),
-                                   (2048 + 64, 768, 2304)])
+                                   (2048 + 64, 768, 2304),
+                                   # partial edge tiles (GPT-2 XL d = 1600, odd small shapes)
+                                   (4096, 1600, 1600), (2048, 4800, 1600), (1024, 1600, 6400), (512, 72, 264)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_linear_wgrad_matches_fp32(M, I, J, bias):
     ext = _ext.require()
