@@ -338,7 +338,10 @@ at::Tensor attention_dropout_mask(int64_t B, int64_t H, int64_t T, double dropou
 bool wgrad_supported(int64_t M, int64_t I, int64_t J) { return pda::wgrad_supported((int)M, (int)I, (int)J); }
 
 // dW[I, J] = dy[M, I]^T . x[M, J] and (optionally) db[I] = column sums of dy, both bf16.
-std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, bool want_bias) {
+// With `out` the weight gradient is written into that tensor (a slice of a reducer's flat
+// gradient buffer) instead of a fresh one — added to its contents when `accumulate` is set.
+std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, bool want_bias,
+                                     const std::optional<at::Tensor>& out, bool accumulate) {
   TORCH_CHECK(dy.is_cuda() && x.is_cuda() && dy.dim() == 2 && x.dim() == 2, "wgrad: 2-D GPU tensors");
   TORCH_CHECK(dy.scalar_type() == at::kBFloat16 && x.scalar_type() == at::kBFloat16, "wgrad: bf16 only");
   TORCH_CHECK(dy.stride(1) == 1 && x.stride(1) == 1, "wgrad: rows must be contiguous");
@@ -358,8 +361,18 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
   pda::wgrad_gemm(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), partial.data_ptr<float>(),
                   want_bias ? bpartial.data_ptr<float>() : nullptr, (int)M, (int)I, (int)J, S, stream);
   check_launch("wgrad_gemm");
-  at::Tensor dw = at::empty({I, J}, dy.options());
-  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, pda::kBF16, dw.data_ptr(), false, stream);
+  at::Tensor dw;
+  if (out.has_value()) {
+    dw = *out;
+    TORCH_CHECK(dw.is_cuda() && dw.is_contiguous() && dw.numel() == I * J &&
+                    (dw.scalar_type() == at::kBFloat16 || dw.scalar_type() == at::kFloat),
+                "wgrad: out must be a contiguous bf16/fp32 GPU tensor with ", I * J, " elements");
+  } else {
+    TORCH_CHECK(!accumulate, "wgrad: accumulate needs an out tensor");
+    dw = at::empty({I, J}, dy.options());
+  }
+  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, dw.scalar_type() == at::kFloat ? pda::kF32 : pda::kBF16,
+                    dw.data_ptr(), accumulate, stream);
   at::Tensor db;
   if (want_bias) {
     db = at::empty({I}, dy.options());
@@ -373,7 +386,8 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
 
 void bind_ops(py::module_& m) {
   m.def("wgrad_supported", &wgrad_supported);
-  m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"));
+  m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"),
+        py::arg("out") = py::none(), py::arg("accumulate") = false);
   m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
         py::arg("bias"), py::arg("eps"), py::arg("rms"));
   m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"),

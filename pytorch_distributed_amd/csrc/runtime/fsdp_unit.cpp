@@ -119,6 +119,7 @@ class ShardedUnit {
     full_grad_ = make_resizable(padded_numel_, opts);
     release_storage(full_grad_);
     grad_written_.assign(params_.size(), false);
+    sunk_.assign(params_.size(), false);
     counted_.assign(params_.size(), false);
     install_hooks();
   }
@@ -202,6 +203,12 @@ class ShardedUnit {
   int64_t num_allgathers() const { return num_allgathers_; }
   int64_t num_reductions() const { return num_reductions_; }
   bool reshard_after_forward = true;  // FULL_SHARD non-root units; the wrapper clears it for the root
+
+  // Gradient sink: hands an op the slice of the flat gradient buffer that belongs to parameter
+  // `i`, so the op's weight-gradient kernel writes (or, second element true, accumulates) there
+  // directly and the per-parameter copy of the hook below disappears. The op then returns an
+  // uninitialised placeholder gradient to autograd purely to make the accumulator hook fire.
+  std::pair<at::Tensor, bool> grad_slot(size_t i);
 
  private:
   friend class ShardedRuntime;
@@ -293,7 +300,7 @@ class ShardedUnit {
   bool unsharded_ = false, ag_issued_ = false;
   c10::intrusive_ptr<c10d::Work> ag_work_, rs_work_;
   bool grad_allocated_ = false, reduce_launched_ = false, unit_done_ = false;
-  std::vector<bool> grad_written_, counted_;
+  std::vector<bool> grad_written_, counted_, sunk_;
   size_t pending_ = 0;
   ShardedRuntime* runtime_ = nullptr;
 
@@ -351,12 +358,32 @@ class ShardedRuntime {
   bool pre_backward_seen_ = false;
 };
 
+std::pair<at::Tensor, bool> ShardedUnit::grad_slot(size_t i) {
+  TORCH_CHECK(runtime_ != nullptr, "ShardedUnit: grad_slot before the unit joined a runtime");
+  TORCH_CHECK(i < params_.size(), "ShardedUnit: bad parameter index");
+  std::lock_guard<std::mutex> lock(runtime_->mu_);
+  at::NoGradGuard ng;
+  if (!grad_allocated_) {
+    allocate_storage(full_grad_, padded_numel_);
+    full_grad_.zero_();
+    grad_allocated_ = true;
+  }
+  at::Tensor slot = full_grad_.narrow(0, offsets_[i], params_[i].numel()).view(params_[i].sizes());
+  const bool accumulate = grad_written_[i];
+  grad_written_[i] = true;
+  sunk_[i] = true;
+  return {slot, accumulate};
+}
+
 void ShardedUnit::on_grad_ready(size_t i) {
   TORCH_CHECK(runtime_ != nullptr, "ShardedUnit: gradient arrived before the unit joined a runtime");
   std::lock_guard<std::mutex> lock(runtime_->mu_);
   if (!runtime_->in_pass_) runtime_->begin_pass();
   at::Tensor& g = params_[i].mutable_grad();
-  if (g.defined()) {
+  if (g.defined() && sunk_[i]) {
+    sunk_[i] = false;  // the op already wrote this gradient into the flat buffer
+    g.reset();
+  } else if (g.defined()) {
     at::NoGradGuard ng;
     if (!grad_allocated_) {
       allocate_storage(full_grad_, padded_numel_);
@@ -401,6 +428,7 @@ void bind_fsdp(py::module_& m) {
       .def("shard_lowp", &ShardedUnit::shard_lowp)
       .def("full_param", &ShardedUnit::full_param)
       .def("set_flat_param", &ShardedUnit::set_flat_param)
+      .def("grad_slot", &ShardedUnit::grad_slot, py::arg("index"))
       .def("params", &ShardedUnit::params)
       .def("offsets", &ShardedUnit::offsets)
       .def_property_readonly("shard_numel", &ShardedUnit::shard_numel)

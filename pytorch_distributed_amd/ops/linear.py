@@ -12,8 +12,8 @@ weight gradient.
   (split-K over tokens, transposed LDS operand reads), which also returns the bias gradient
   as a by-product instead of a separate reduction pass over ``dY``.
 
-Shapes the native paths do not cover (non-bf16, dimensions not multiples of 256 for the
-weight gradient, e.g. d = 1600) and CPU tensors use ``torch`` matmuls.
+Shapes the native paths do not cover (non-bf16, dimensions that are not multiples of 8, token
+counts that are not multiples of 32) and CPU tensors use ``torch`` matmuls.
 ``PDA_NO_NATIVE_WGRAD=1`` / ``PDA_NO_GEMM_PLANNER=1`` switch the two native paths off
 (A/B measurements).
 """
@@ -64,6 +64,9 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        # Gradient sink: a sharding / reducing wrapper that owns a flat gradient buffer tags the
+        # weight with a callable returning (slice_of_flat_buffer, accumulate).
+        ctx.grad_sink = getattr(weight, "_pda_grad_sink", None)
         x2 = x.reshape(-1, x.shape[-1])
         y = planned_mm(x2, weight, trans_b=True, bias=bias)
         return y.view(*x.shape[:-1], weight.shape[0])
@@ -80,7 +83,16 @@ class _LinearFn(torch.autograd.Function):
         if need_w and _native_wgrad_ok(dy2, x2):
             if not dy2.is_contiguous():
                 dy2 = dy2.contiguous()
-            dw, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b))
+            sink = ctx.grad_sink
+            if sink is not None:
+                # The kernel's slice-reduction pass writes straight into the flat buffer; autograd
+                # gets an uninitialised placeholder whose only job is to fire the owner's hook
+                # (allocation only, no kernel touches it).
+                slot, accumulate = sink()
+                _, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), slot, accumulate)
+                dw = torch.empty_like(weight)
+            else:
+                dw, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b))
             if need_b:
                 db = db_native
         else:

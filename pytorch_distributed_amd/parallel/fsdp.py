@@ -21,6 +21,8 @@ native autograd hooks.
 """
 from __future__ import annotations
 
+import functools
+
 import contextlib
 import enum
 from typing import Dict, Iterator, List, Optional, Tuple
@@ -85,6 +87,12 @@ class FSDP(nn.Module):
 
         ext = _ext.require()
         self.unit = ext.ShardedUnit(mine, self.process_group, self.sharding_strategy.value, force_collectives)
+        # Weight matrices hand ops.linear a slice of this unit's flat gradient buffer, so the
+        # weight-gradient kernel writes there directly instead of producing a tensor that the
+        # gradient hook then copies (one copy kernel per parameter and micro-batch).
+        for i, p in enumerate(mine):
+            if p.dim() == 2:
+                p._pda_grad_sink = functools.partial(self.unit.grad_slot, i)
         # The flat shard is deliberately NOT registered as a module parameter (plain attribute,
         # bypassing nn.Module.__setattr__): state_dict() keeps the original names, .to() never
         # touches it, and parameters() is overridden below to return it.
