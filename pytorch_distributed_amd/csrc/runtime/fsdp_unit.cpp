@@ -380,9 +380,9 @@ void ShardedUnit::on_grad_ready(size_t i) {
   std::lock_guard<std::mutex> lock(runtime_->mu_);
   if (!runtime_->in_pass_) runtime_->begin_pass();
   at::Tensor& g = params_[i].mutable_grad();
-  if (g.defined() && sunk_[i]) {
+  if (sunk_[i]) {
     sunk_[i] = false;  // the op already wrote this gradient into the flat buffer
-    g.reset();
+    if (g.defined()) g.reset();
   } else if (g.defined()) {
     at::NoGradGuard ng;
     if (!grad_allocated_) {

@@ -83,14 +83,17 @@ class _LinearFn(torch.autograd.Function):
         if need_w and _native_wgrad_ok(dy2, x2):
             if not dy2.is_contiguous():
                 dy2 = dy2.contiguous()
-            sink = ctx.grad_sink
-            if sink is not None:
-                # The kernel's slice-reduction pass writes straight into the flat buffer; autograd
-                # gets an uninitialised placeholder whose only job is to fire the owner's hook
-                # (allocation only, no kernel touches it).
-                slot, accumulate = sink()
+            target = ctx.grad_sink() if ctx.grad_sink is not None else None
+            if target is None and weight.grad is not None and weight.grad.is_contiguous():
+                # Gradient accumulation without a wrapper: add into the existing .grad in the
+                # kernel's reduction pass rather than materialise dW for autograd to add.
+                target = (weight.grad, True)
+            if target is not None:
+                # The kernel's slice-reduction pass writes straight into the owner's flat buffer.
+                # Autograd gets no weight gradient (None): the parameter's accumulator node still
+                # runs, so the owner's hook on it fires and counts the parameter as ready.
+                slot, accumulate = target
                 _, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), slot, accumulate)
-                dw = torch.empty_like(weight)
             else:
                 dw, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b))
             if need_b:

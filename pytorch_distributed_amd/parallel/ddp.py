@@ -17,6 +17,7 @@ buffers cost 36 MiB of broadcast per forward) and the unused-parameter graph sea
 from __future__ import annotations
 
 import contextlib
+import functools
 from typing import Optional
 
 import torch
@@ -28,6 +29,12 @@ from . import comm
 
 DEFAULT_BUCKET_CAP_MB = 64.0
 DEFAULT_FIRST_BUCKET_MB = 4.0
+
+
+def _bucket_slot(p):
+    """(gradient tensor to accumulate into, accumulate=True) or None when ``p.grad`` was dropped."""
+    g = p.grad
+    return None if g is None else (g, True)
 
 
 class DDP(nn.Module):
@@ -61,6 +68,10 @@ class DDP(nn.Module):
                                        int(first_bucket_mb * 2**20), force_collectives)
         for p in params:
             p._pda_grad_is_view = True  # optimizers must zero these in place, never drop them
+            if p.dim() == 2:
+                # ops.linear adds its weight gradient straight into the bucket view instead of
+                # materialising it for autograd to add (the hook on the accumulator still fires).
+                p._pda_grad_sink = functools.partial(_bucket_slot, p)
 
     # -- module surface ----------------------------------------------------------------
     def forward(self, *args, **kwargs):
