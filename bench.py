@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="single GPU: record the whole optimizer step into a HIP graph and replay it")
     ap.add_argument("--wrap-single", action="store_true",
                     help="with --gpus 1: still wrap in DDP/FSDP and force the RCCL collectives (rehearsal)")
     return ap.parse_args()
@@ -97,7 +99,9 @@ def main():
             kw = {} if args.fsdp_unit_blocks is None else {"unit_blocks": args.fsdp_unit_blocks}
             model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], force_collectives=args.wrap_single, **kw)
             parallelism = f"fsdp_{args.strategy.lower()}{world}"
-    optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1)
+    if args.hip_graph and distributed:
+        raise SystemExit("--hip-graph is a single-process mode")
+    optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1, capturable=args.hip_graph)
 
     if args.batch_per_gpu % args.micro_batch != 0:
         raise SystemExit("--batch-per-gpu must be a multiple of --micro-batch")
@@ -115,6 +119,17 @@ def main():
             else:
                 (model(inputs, targets) / accum).backward()
         optimizer.step(zero_grad=True)
+
+    if args.hip_graph:
+        from pytorch_distributed_amd.utils.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer, args.micro_batch, args.seq_len, accum, warmup_steps=2)
+
+        def one_step():  # noqa: F811 - replaces the eager step above
+            xs, ys = zip(*(next(loader) for _ in range(accum)))
+            graphed(torch.stack(xs), torch.stack(ys))
+
+        for _ in range(3):  # 2 eager warm-up steps + the capture happen before the timed region
+            one_step()
 
     def fence():
         if distributed:
@@ -141,7 +156,7 @@ def main():
     mfu = tps * fpt / (world * MI355X_PEAK_BF16_FLOPS)
     if rank == 0:
         print(json.dumps({
-            "metric": "tokens/sec (whole job), GPT-2-large training, bf16", "value": tps, "unit": "tokens/s",
+            "metric": f"tokens/sec (whole job), {_pretty(args.model)} training, {args.dtype}", "value": tps, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -150,10 +165,15 @@ def main():
             "config": {"model": args.model, "global_batch": global_batch, "micro_batch": args.micro_batch,
                        "grad_accum": accum, "seq_len": args.seq_len, "parallelism": parallelism,
                        "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
-                       "flops_per_token": fpt, "tuned_gemm_table": tuned},
+                       "flops_per_token": fpt, "tuned_gemm_table": tuned, "hip_graph": bool(args.hip_graph)},
         }), flush=True)
     if distributed:
         dist.destroy_process_group()
+
+
+def _pretty(model_name: str) -> str:
+    return {"gpt2": "GPT-2-small", "gpt2-medium": "GPT-2-medium", "gpt2-large": "GPT-2-large",
+            "gpt2-xl": "GPT-2-XL"}.get(model_name, model_name)
 
 
 class _cfg_holder:

@@ -214,7 +214,8 @@ at::Tensor cross_entropy_fwd_bwd(at::Tensor logits, const at::Tensor& targets, i
 void adamw_step(const std::vector<at::Tensor>& params, const std::vector<std::optional<at::Tensor>>& lowp,
                 const std::vector<at::Tensor>& grads, const std::vector<at::Tensor>& exp_avg,
                 const std::vector<at::Tensor>& exp_avg_sq, double lr, double beta1, double beta2,
-                double eps, double weight_decay, int64_t step, double grad_scale, bool zero_grad) {
+                double eps, double weight_decay, int64_t step, double grad_scale, bool zero_grad,
+                const std::optional<at::Tensor>& dynamic) {
   const size_t n = params.size();
   TORCH_CHECK(grads.size() == n && exp_avg.size() == n && exp_avg_sq.size() == n && lowp.size() == n,
               "adamw: list lengths differ");
@@ -259,6 +260,12 @@ void adamw_step(const std::vector<at::Tensor>& params, const std::vector<std::op
   hp.bias_correction1 = (float)(1.0 - std::pow(beta1, (double)step));
   hp.bias_correction2 = (float)(1.0 - std::pow(beta2, (double)step));
   hp.grad_scale = (float)grad_scale;
+  if (dynamic.has_value()) {  // device-resident {1 - lr*wd, lr/bc1, 1/sqrt(bc2)}: HIP-graph capture
+    TORCH_CHECK(dynamic->is_cuda() && dynamic->scalar_type() == at::kFloat && dynamic->numel() >= 3 &&
+                    dynamic->is_contiguous(),
+                "adamw: dynamic must be a contiguous float32 GPU tensor with 3 elements");
+    hp.dynamic = dynamic->data_ptr<float>();
+  }
   pda::adamw_step(ts.data(), (int)n, gdt, hp, zero_grad, current_stream());
   check_launch("adamw_step");
 }
@@ -401,7 +408,7 @@ void bind_ops(py::module_& m) {
   m.def("adamw_step", &adamw_step, py::arg("params"), py::arg("lowp"), py::arg("grads"),
         py::arg("exp_avg"), py::arg("exp_avg_sq"), py::arg("lr"), py::arg("beta1"), py::arg("beta2"),
         py::arg("eps"), py::arg("weight_decay"), py::arg("step"), py::arg("grad_scale"),
-        py::arg("zero_grad"));
+        py::arg("zero_grad"), py::arg("dynamic") = py::none());
   m.def("accumulate_bf16_into_f32", &accumulate_bf16_into_f32);
   m.def("attention_forward", &attention_forward, py::arg("qkv"), py::arg("num_heads"),
         py::arg("softmax_scale"), py::arg("dropout_p") = 0.0, py::arg("seed") = 0);

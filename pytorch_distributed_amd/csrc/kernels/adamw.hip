@@ -32,7 +32,20 @@ struct Scalars {
   float inv_sqrt_bc2;
   float eps;
   float grad_scale;
+  // Optional device-resident overrides {decay, step_size, inv_sqrt_bc2}: the step-dependent
+  // scalars of a step captured in a HIP graph cannot be kernel arguments (they would be frozen
+  // at capture), so a captured step computes them on the device and the kernels read them here.
+  const float* dynamic;
 };
+
+__device__ __forceinline__ Scalars resolve(Scalars s) {
+  if (s.dynamic != nullptr) {
+    s.decay = s.dynamic[0];
+    s.step_size = s.dynamic[1];
+    s.inv_sqrt_bc2 = s.dynamic[2];
+  }
+  return s;
+}
 
 template <typename GradT>
 __device__ __forceinline__ void load_grad8(const GradT* g, float (&out)[8]);
@@ -121,7 +134,8 @@ __device__ __forceinline__ void adam_range(const AdamWTensor& t, int64_t begin, 
 }
 
 template <typename GradT, bool kZeroGrad>
-__global__ __launch_bounds__(kThreads) void adamw_flat_kernel(AdamWTensor t, Scalars s) {
+__global__ __launch_bounds__(kThreads) void adamw_flat_kernel(AdamWTensor t, Scalars s_in) {
+  const Scalars s = resolve(s_in);
   const int64_t stride = int64_t(gridDim.x) * kThreads * 8;
   adam_range<GradT, kZeroGrad>(t, int64_t(blockIdx.x) * kThreads * 8, t.numel, stride, s);
 }
@@ -133,7 +147,8 @@ struct PackedArgs {
 };
 
 template <typename GradT, bool kZeroGrad>
-__global__ __launch_bounds__(kThreads) void adamw_packed_kernel(PackedArgs a, Scalars s) {
+__global__ __launch_bounds__(kThreads) void adamw_packed_kernel(PackedArgs a, Scalars s_in) {
+  const Scalars s = resolve(s_in);
   const AdamWTensor& t = a.tensors[a.block_tensor[blockIdx.x]];
   const int64_t begin = int64_t(a.block_chunk[blockIdx.x]) * kChunk;
   const int64_t end = (begin + kChunk < t.numel) ? begin + kChunk : t.numel;
@@ -188,6 +203,7 @@ void adamw_step(const AdamWTensor* tensors, int n, DType grad_dtype, const AdamW
   s.inv_sqrt_bc2 = 1.f / sqrtf(hp.bias_correction2);
   s.eps = hp.eps;
   s.grad_scale = hp.grad_scale;
+  s.dynamic = hp.dynamic;
   if (grad_dtype == kBF16) {
     if (zero_grad) launch_all<bf16_raw, true>(tensors, n, s, stream);
     else launch_all<bf16_raw, false>(tensors, n, s, stream);

@@ -24,6 +24,9 @@ struct AdamWHyper {
   float bias_correction1;  // 1 - beta1^t
   float bias_correction2;  // 1 - beta2^t
   float grad_scale;        // gradients are multiplied by this before use
+  // Optional device array {1 - lr*wd, lr / bias_correction1, 1 / sqrt(bias_correction2)} that
+  // overrides lr / weight_decay / bias_correction* above (HIP-graph capture: see adamw.hip).
+  const float* dynamic = nullptr;
 };
 
 // One tensor of a multi-tensor AdamW step. `param` is the fp32 value that is

@@ -32,7 +32,7 @@ from .. import _ext
 
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, amsgrad: bool = False):
+                 weight_decay: float = 1e-2, amsgrad: bool = False, capturable: bool = False):
         if amsgrad:
             raise ValueError("FusedAdamW does not implement amsgrad")
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
@@ -40,6 +40,12 @@ class FusedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False)
         super().__init__(params, defaults)
         self._grads_cleared_by_step = False
+        # capturable: the step-dependent scalars (bias corrections, lr) live in device memory and
+        # are advanced by device ops, so a step recorded in a HIP graph stays correct when the
+        # graph is replayed (utils/graphs.py). Host-side step counters are caught up lazily.
+        self.capturable = capturable
+        self._capture: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._pending_host_steps = 0
 
     # ------------------------------------------------------------------ state
     def _init_state(self, p: torch.Tensor) -> Dict[str, Any]:
@@ -64,6 +70,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._catch_up_host_steps()
+        self._step_serial = getattr(self, "_step_serial", 0) + 1
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             gpu: Dict[tuple, List] = {}
@@ -102,14 +110,58 @@ class FusedAdamW(torch.optim.Optimizer):
                         lst.append(item)
                 else:
                     self._reference_update(p, grad, st, group, step_val, grad_scale, zero_grad and not drop)
-            for (gdtype, step_i, _dev, zero_here), (masters, lowps, grads, m, v) in gpu.items():
+            for (gdtype, step_i, dev, zero_here), (masters, lowps, grads, m, v) in gpu.items():
+                dyn = self._advance_capture_scalars(group, dev, step_i) if self.capturable else None
                 _ext.require().adamw_step(masters, lowps, grads, m, v, group["lr"], beta1, beta2,
                                           group["eps"], group["weight_decay"], step_i, grad_scale,
-                                          zero_here)
+                                          zero_here, dyn)
             for p in drop_after:
                 p.grad = None
         self._grads_cleared_by_step = zero_grad
         return loss
+
+    # ------------------------------------------------------------------ HIP-graph capture
+    def _advance_capture_scalars(self, group, device, host_step: int) -> torch.Tensor:
+        """Device-side ``step += 1`` and the three scalars the kernels read ({1 - lr*wd, lr/bc1,
+        1/sqrt(bc2)}). Everything here is device work, so it is recorded by a graph capture and
+        re-executed by every replay; only the learning rate comes from the host, through
+        :meth:`refresh_capture_scalars`."""
+        key = (id(group), str(device))
+        cap = self._capture.get(key)
+        if cap is None:
+            cap = {"step": torch.full((), float(host_step - 1), dtype=torch.float32, device=device),
+                   "lr": torch.full((), float(group["lr"]), dtype=torch.float32, device=device),
+                   "dyn": torch.zeros(3, dtype=torch.float32, device=device), "group": group}
+            self._capture[key] = cap
+        elif not torch.cuda.is_current_stream_capturing():
+            cap["lr"].fill_(float(group["lr"]))
+        if cap.get("serial") == self._step_serial:  # a second kernel list of the same group and step
+            return cap["dyn"]
+        cap["serial"] = self._step_serial
+        beta1, beta2 = group["betas"]
+        cap["step"].add_(1.0)
+        bc1 = 1.0 - torch.pow(beta1, cap["step"])
+        bc2 = 1.0 - torch.pow(beta2, cap["step"])
+        torch.stack([1.0 - cap["lr"] * group["weight_decay"], cap["lr"] / bc1, torch.rsqrt(bc2)], out=cap["dyn"])
+        return cap["dyn"]
+
+    def refresh_capture_scalars(self) -> None:
+        """Copy each group's current learning rate to the device (call before replaying a
+        captured step; a scheduler changes ``group['lr']`` on the host only)."""
+        for cap in self._capture.values():
+            cap["lr"].fill_(float(cap["group"]["lr"]))
+
+    def note_replayed_steps(self, n: int = 1) -> None:
+        """A captured step was replayed ``n`` times: the host-side per-parameter step counters
+        (checkpoint state) are caught up the next time they are looked at."""
+        self._pending_host_steps += n
+
+    def _catch_up_host_steps(self) -> None:
+        if self._pending_host_steps:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] += self._pending_host_steps
+            self._pending_host_steps = 0
 
     @staticmethod
     def _reference_update(p, grad, st, group, step, grad_scale, zero_grad):
@@ -156,6 +208,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def state_dict(self):
         """torch.optim.AdamW layout; the fp32 master copy of a bf16 parameter is stored under
         the extra per-parameter key ``master`` (ignored by stock AdamW on load)."""
+        self._catch_up_host_steps()
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
