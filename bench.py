@@ -54,6 +54,12 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # The contract is ONE JSON line on stdout. Libraries print banners of their own there
+    # (RCCL's version block, process-group messages), so everything written to fd 1 while the
+    # benchmark runs is sent to stderr and the result line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -155,7 +161,7 @@ def main():
     fpt = model_flops_per_token(_cfg_holder(cfg), args.seq_len)
     mfu = tps * fpt / (world * MI355X_PEAK_BF16_FLOPS)
     if rank == 0:
-        print(json.dumps({
+        result_line = json.dumps({
             "metric": f"tokens/sec (whole job), {_pretty(args.model)} training, {args.dtype}", "value": tps, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -166,7 +172,9 @@ def main():
                        "grad_accum": accum, "seq_len": args.seq_len, "parallelism": parallelism,
                        "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
                        "flops_per_token": fpt, "tuned_gemm_table": tuned, "hip_graph": bool(args.hip_graph)},
-        }), flush=True)
+        })
+        sys.stdout.flush()
+        os.write(real_stdout, (result_line + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
