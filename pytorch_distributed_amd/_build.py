@@ -56,7 +56,8 @@ def _hash(paths, flags) -> str:
 def _compile(src: Path, cmd_prefix, flags, deps, force, verbose):
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     rel = src.relative_to(CSRC)
-    obj = OBJ_DIR / ("_".join(rel.parts) + ".o")
+    tag = "asan_" if any("-fsanitize" in f for f in flags) else ""  # flavours keep separate objects
+    obj = OBJ_DIR / (tag + "_".join(rel.parts) + ".o")
     stamp = obj.with_suffix(".hash")
     digest = _hash([src, *deps], [*cmd_prefix, *flags])
     if not force and obj.exists() and stamp.exists() and stamp.read_text() == digest:
@@ -71,8 +72,15 @@ def _compile(src: Path, cmd_prefix, flags, deps, force, verbose):
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every native source for gfx950 and link ``_C.so``. Returns its path."""
+def build(force: bool = False, verbose: bool = False, sanitize: bool = False) -> Path:
+    """Compile every native source for gfx950 and link ``_C.so``. Returns its path.
+
+    ``sanitize=True`` is the debugging flavour: the host-side C++ (bindings + runtime) is built
+    with AddressSanitizer and UndefinedBehaviorSanitizer into ``build/asan/_C.so`` (the in-tree
+    library is left alone; GPU code is never sanitized). Run it on the CPU with
+    ``LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0
+    PYTHONPATH=build/asan-overlay python -m pytest tests -m "not gpu"`` — see
+    ``tools/run_asan_tests.sh``."""
     hipcc = shutil.which("hipcc") or str(ROCM / "bin" / "hipcc")
     cxx = shutil.which("g++") or "g++"
     inc, torch_lib, cxx11 = _torch_paths()
@@ -93,6 +101,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                   "-DTORCH_API_INCLUDE_EXTENSION_H", f"-I{CSRC}", f"-I{py_inc}",
                   *[f"-isystem{p}" for p in inc]]
 
+    target = TARGET
+    if sanitize:
+        host_flags = [f for f in host_flags if f != "-O2"] + ["-O1", "-g", "-fno-omit-frame-pointer",
+                                                              "-fsanitize=address,undefined"]
+        target = REPO / "build" / "asan" / "_C.so"
+        target.parent.mkdir(parents=True, exist_ok=True)
+
     jobs = int(os.environ.get("MAX_JOBS", "0")) or min(8, os.cpu_count() or 1)
     tasks = [(s, [hipcc], hip_flags, kernel_hdrs) for s in kernel_srcs]
     tasks += [(s, [cxx], host_flags, host_hdrs) for s in host_srcs]
@@ -101,6 +116,19 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objs = [str(o) for o, _ in results]
     rebuilt = any(r for _, r in results)
 
+    if sanitize:
+        # g++ drives this link so that its own sanitizer runtimes are the ones pulled in; the
+        # kernel objects only need the HIP runtime that PyTorch ships.
+        link = [cxx, "-shared", "-fPIC", "-fsanitize=address,undefined", "-o", str(target), *objs,
+                f"-L{torch_lib}", f"-Wl,-rpath,{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+                "-ltorch", "-ltorch_python", str(Path(torch_lib) / "libhipblaslt.so"),
+                str(Path(torch_lib) / "libamdhip64.so"), "-lpthread", "-ldl"]
+        if verbose:
+            print("[build]", " ".join(link), flush=True)
+        proc = subprocess.run(link, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"link failed:\n{proc.stdout}\n{proc.stderr}")
+        return target
     if rebuilt or force or not TARGET.exists():
         link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(TARGET), *objs,
                 f"-L{torch_lib}", f"-Wl,-rpath,{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu",
@@ -117,5 +145,5 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    out = build(force="--force" in sys.argv, verbose=True)
+    out = build(force="--force" in sys.argv, verbose=True, sanitize="--sanitize" in sys.argv)
     print(f"built {out}")

@@ -29,6 +29,8 @@
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
+#include "comm_debug.h"
+
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -145,7 +147,9 @@ class ShardedUnit {
     } else {
       at::Tensor out = full_param_;
       at::Tensor in = src;
+      pda::comm_debug::before(pg_, pda::comm_debug::kAllGather, out.numel(), debug_sequence_, out, "ShardedUnit");
       ag_work_ = pg_->_allgather_base(out, in);
+      pda::comm_debug::after(ag_work_, out);
       ++num_allgathers_;
     }
     ag_issued_ = true;
@@ -244,7 +248,9 @@ class ShardedUnit {
         std::vector<at::Tensor> ts{full_grad_};
         c10d::AllreduceOptions opts;
         opts.reduceOp = native_avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
+        pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, full_grad_.numel(), debug_sequence_, full_grad_, "ShardedUnit");
         rs_work_ = pg_->allreduce(ts, opts);
+        pda::comm_debug::after(rs_work_, full_grad_);
         ++num_reductions_;
       }
     } else if (world_ == 1 && !force_collectives_) {
@@ -254,7 +260,9 @@ class ShardedUnit {
       c10d::ReduceScatterOptions opts;
       opts.reduceOp = native_avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
       at::Tensor in = full_grad_;
+      pda::comm_debug::before(pg_, pda::comm_debug::kReduceScatter, in.numel(), debug_sequence_, in, "ShardedUnit");
       rs_work_ = pg_->_reduce_scatter_base(reduced_, in, opts);
+      pda::comm_debug::after(rs_work_, in);
       ++num_reductions_;
     }
   }
@@ -306,7 +314,7 @@ class ShardedUnit {
 
   std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
   std::vector<uintptr_t> hook_keys_;
-  int64_t num_allgathers_ = 0, num_reductions_ = 0;
+  int64_t num_allgathers_ = 0, num_reductions_ = 0, debug_sequence_ = 0;
 };
 
 class ShardedRuntime {

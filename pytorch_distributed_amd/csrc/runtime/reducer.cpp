@@ -31,6 +31,8 @@
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
+#include "comm_debug.h"
+
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -227,7 +229,9 @@ class GradReducer {
     c10d::AllreduceOptions opts;
     const bool native_avg = backend_ == "nccl";
     opts.reduceOp = native_avg ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
+    pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, b.flat.numel(), debug_sequence_, b.flat, "GradReducer");
     b.work = pg_->allreduce(tensors, opts);
+    pda::comm_debug::after(b.work, b.flat);
     ++num_collectives_;
   }
 
@@ -262,7 +266,7 @@ class GradReducer {
   std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
   std::vector<uintptr_t> hook_keys_;
   std::mutex mu_;
-  int64_t num_collectives_ = 0;
+  int64_t num_collectives_ = 0, debug_sequence_ = 0;
   int64_t num_rebound_ = 0;
 };
 

@@ -109,3 +109,36 @@ def _ddp_set_to_none(rank, world):
 
 def test_ddp_survives_set_to_none():
     run_distributed(_ddp_set_to_none, world=2)
+
+
+def _comm_debug_modes(rank, world):
+    """PDA_COMM_DEBUG / PDA_COMM_SERIALIZE: same gradients with the cross-rank agreement check and
+    with every collective waited for at once; a rank that is about to issue a different collective
+    (here: different bucket boundaries) gets an error instead of a hang."""
+    import os
+
+    os.environ["PDA_COMM_DEBUG"] = "1"
+    os.environ["PDA_COMM_SERIALIZE"] = "1"
+    from pytorch_distributed_amd.parallel import DDP, FSDP, ShardingStrategy
+
+    ref = _tiny_model(3)
+    x, y = _batch(11, 2 * world)
+    ref(x, y).backward()
+    model = copy.deepcopy(ref)
+    model.zero_grad()
+    ddp = DDP(model, bucket_cap_mb=0.25)
+    ddp(x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]).backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=2e-4, atol=2e-6, msg=lambda m: f"{n}: {m}")
+
+    sharded = FSDP(copy.deepcopy(ref).requires_grad_(True), sharding_strategy=ShardingStrategy.FULL_SHARD)
+    sharded(x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]).backward()
+
+    # mismatch: rank 1 builds different buckets -> its first all-reduce has a different size
+    bad = DDP(copy.deepcopy(ref), bucket_cap_mb=0.25 if rank == 0 else 0.11, first_bucket_mb=0.05 if rank == 0 else 0.02)
+    with pytest.raises(RuntimeError, match="collective mismatch"):
+        bad(x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]).backward()
+
+
+def test_comm_debug_modes():
+    run_distributed(_comm_debug_modes, world=2)
