@@ -37,6 +37,8 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
     ap.add_argument("--synthetic-data", action="store_true", help="random tokens generated on the device")
     ap.add_argument("--data-dir", default=".cache/data/fineweb10B")
     ap.add_argument("--num-train-files", type=int, default=10)
+    ap.add_argument("--prefetch-data", action="store_true",
+                    help="distributed scripts: read shards through the native mmap + prefetch-thread loader")
     ap.add_argument("--make-synthetic-shards", action="store_true",
                     help="write random .bin shards into --data-dir instead of downloading")
     ap.add_argument("--no-profile", action="store_true")
@@ -91,7 +93,8 @@ def build_loader(args, cfg, device, distributed: bool, rank: int = 0):
                                     seed=1234 + rank)
     files = train_files(args)
     if distributed:
-        return DistributedKJJ0DataLoader(files, args.micro_batch_size, args.sequence_length, device)
+        return DistributedKJJ0DataLoader(files, args.micro_batch_size, args.sequence_length, device,
+                                         prefetch=getattr(args, "prefetch_data", False))
     return KJJ0DataLoader(files, args.micro_batch_size, args.sequence_length, device)
 
 

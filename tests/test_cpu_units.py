@@ -116,6 +116,17 @@ def test_native_prefetcher_matches_python_loader(tmp_path):
             assert torch.equal(x, wx) and torch.equal(y, wy)
 
 
+def test_loader_prefetch_option_matches_python_path(tmp_path):
+    paths = _shards(tmp_path, [3000, 2500])
+    for rank in range(2):
+        want = list(DistributedKJJ0DataLoader(paths, 2, 16, "cpu", rank=rank, world_size=2, verbose=False))
+        got = list(DistributedKJJ0DataLoader(paths, 2, 16, "cpu", rank=rank, world_size=2, verbose=False,
+                                             prefetch=True))
+        assert len(got) == len(want) > 0
+        for (x, y), (wx, wy) in zip(got, want):
+            assert torch.equal(x, wx) and torch.equal(y, wy)
+
+
 def test_synthetic_files_and_loader(tmp_path):
     files = make_synthetic_fineweb_files(tmp_path, num_train_files=2, tokens_per_file=4096)
     assert [f.name for f in files] == ["fineweb_val_000000.bin", "fineweb_train_000001.bin", "fineweb_train_000002.bin"]
