@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
+    ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",
                     help="single GPU: record the whole optimizer step into a HIP graph and replay it")
     ap.add_argument("--wrap-single", action="store_true",
@@ -175,6 +176,12 @@ def main():
         })
         sys.stdout.flush()
         os.write(real_stdout, (result_line + "\n").encode())
+    if args.planner_stats and rank == 0:
+        from pytorch_distributed_amd import _ext
+        st = _ext.require().gemm_planner_stats()
+        for row in sorted(st["table"]):
+            print("planner m=%d n=%d k=%d ta=%d tb=%d ep=%d candidates=%d chosen=%d first=%.1fus best=%.1fus"
+                  % tuple(row), file=sys.stderr)
     if distributed:
         dist.destroy_process_group()
 

@@ -88,8 +88,8 @@ class Planner {
   }
 
   bool tuning = true;
-  int max_candidates = 24;
-  int timed_runs = 3;
+  int max_candidates = 48;
+  int timed_runs = 4;
   size_t workspace_limit = size_t(64) << 20;
 
   void run(const at::Tensor& a, bool trans_a, const at::Tensor& b, bool trans_b, at::Tensor& out, int epilogue,
@@ -306,7 +306,7 @@ void bind_gemm(py::module_& m) {
     p.tuning = tuning;
     p.max_candidates = max_candidates;
     p.timed_runs = timed_runs;
-  }, py::arg("tuning") = true, py::arg("max_candidates") = 24, py::arg("timed_runs") = 3);
+  }, py::arg("tuning") = true, py::arg("max_candidates") = 48, py::arg("timed_runs") = 4);
   m.def("gemm_planner_stats", []() { return Planner::get().stats(); });
 }
 

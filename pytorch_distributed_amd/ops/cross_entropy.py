@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _ext
+from .linear import planned_mm
 
 _PAD = 128
 
@@ -76,7 +77,7 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
         rows = h2.shape[0]
         vp = _padded_cols(V)
         logits = torch.empty(rows, vp, dtype=hidden.dtype, device=hidden.device)
-        torch.mm(h2, weight.t(), out=logits[:, :V])
+        planned_mm(h2, weight, trans_b=True, out=logits[:, :V])
         tgt = targets.reshape(-1).contiguous()
         n_valid = (tgt != ignore_index).sum().clamp_(min=1).to(torch.float32)
         scale = n_valid.reciprocal().reshape(1)
@@ -92,7 +93,7 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
         dlogits = dlogits_p[:, :V]
         dhidden = dweight = None
         if ctx.needs_input_grad[0]:
-            dhidden = torch.mm(dlogits, weight).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
+            dhidden = planned_mm(dlogits, weight).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
         if ctx.needs_input_grad[1]:
             dweight = torch.mm(dlogits.t(), h2).mul_(dloss.to(weight.dtype))
         return dhidden, dweight, None, None
