@@ -320,3 +320,52 @@ def test_memory_estimate_matches_reference_model():
     assert math.isclose(e["params_mb"], 774_030_080 * 4 / 2**20) and math.isclose(e["optimizer_mb"], 2 * e["params_mb"])
     s = estimate_training_memory(774_030_080, "bf16", world_size=8, strategy="FULL_SHARD")
     assert math.isclose(s["total_mb"], 774_030_080 * 16 / 8 / 2**20)
+
+
+def test_planned_mm_cpu_fallback_matches_torch():
+    from pytorch_distributed_amd.ops.linear import planned_mm
+
+    torch.manual_seed(0)
+    a, w, b = torch.randn(6, 8), torch.randn(5, 8), torch.randn(5)
+    torch.testing.assert_close(planned_mm(a, w, trans_b=True, bias=b), torch.nn.functional.linear(a, w, b))
+    torch.testing.assert_close(planned_mm(a, w.t().contiguous()), a @ w.t())
+    out = torch.empty(6, 5)
+    planned_mm(a, w, trans_b=True, out=out)
+    torch.testing.assert_close(out, a @ w.t())
+
+
+def test_attention_dropout_quantisation_and_cpu_path():
+    from pytorch_distributed_amd import ops
+    from pytorch_distributed_amd.ops.attention import dropout_quantised
+
+    assert dropout_quantised(0.0) == (0.0, 1.0)
+    p, scale = dropout_quantised(0.1)
+    assert p == 26 / 256 and abs(scale - 256 / 230) < 1e-12
+    qkv = torch.randn(1, 16, 3 * 2 * 8)
+    torch.manual_seed(5)
+    a = ops.causal_attention(qkv, 2, dropout_p=0.5, training=True)
+    b = ops.causal_attention(qkv, 2, dropout_p=0.5, training=False)
+    assert not torch.equal(a, b) and torch.equal(b, ops.causal_attention(qkv, 2))
+    keep = torch.ones(1, 2, 16, 16, dtype=torch.bool)
+    torch.testing.assert_close(ops.attention_reference(qkv, 2, keep_mask=keep, keep_scale=1.0),
+                               ops.attention_reference(qkv, 2))
+
+
+def test_capturable_adamw_on_cpu_is_plain_adamw_and_graph_step_needs_it():
+    from pytorch_distributed_amd.optim import FusedAdamW
+    from pytorch_distributed_amd.utils.graphs import GraphedTrainStep
+
+    torch.manual_seed(0)
+    w0 = torch.randn(4, 3)
+    p1, p2 = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    o1, o2 = FusedAdamW([p1], lr=1e-2), FusedAdamW([p2], lr=1e-2, capturable=True)
+    for _ in range(3):
+        g = torch.randn(4, 3)
+        p1.grad, p2.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+    torch.testing.assert_close(p1, p2)
+    o2.note_replayed_steps(2)
+    assert int(o2.state_dict()["state"][0]["step"]) == 5
+    with pytest.raises(ValueError, match="capturable"):
+        GraphedTrainStep(torch.nn.Linear(2, 2), o1, 1, 4, device=torch.device("cpu"))
