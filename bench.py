@@ -90,7 +90,11 @@ def main():
 
     cfg = get_config(args.model).without_dropout()
     torch.manual_seed(42)
-    model = MyGPT2LMHeadModel(cfg)
+    if hasattr(cfg, "intermediate_size"):  # Llama-style configuration
+        from pytorch_distributed_amd.models import LlamaForCausalLM
+        model = LlamaForCausalLM(cfg)
+    else:
+        model = MyGPT2LMHeadModel(cfg)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model.to(device=device, dtype=dtype)
 

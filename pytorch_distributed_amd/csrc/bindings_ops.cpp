@@ -341,6 +341,30 @@ at::Tensor attention_dropout_mask(int64_t B, int64_t H, int64_t T, double dropou
   return keep.to(at::kBool);
 }
 
+// ------------------------------------------------------------------- rotary --
+at::Tensor rope_apply(const at::Tensor& qkv, const at::Tensor& cos, const at::Tensor& sin, int64_t num_heads,
+                      bool inverse, bool in_place) {
+  check_gpu(qkv, "qkv");
+  check_gpu(cos, "cos");
+  check_gpu(sin, "sin");
+  TORCH_CHECK(qkv.dim() == 3, "rope: qkv must be [B, T, 3*H*D]");
+  const int64_t B = qkv.size(0), T = qkv.size(1);
+  TORCH_CHECK(qkv.size(2) % (3 * num_heads) == 0, "rope: bad qkv width");
+  const int64_t D = qkv.size(2) / (3 * num_heads);
+  const auto dt = dtype_of(qkv);
+  const int vec = dt == pda::kBF16 ? 8 : 4;
+  TORCH_CHECK(D % 2 == 0 && (D / 2) % vec == 0, "rope: head_dim / 2 must be a multiple of ", vec);
+  TORCH_CHECK(cos.scalar_type() == at::kFloat && sin.scalar_type() == at::kFloat && cos.dim() == 2 &&
+                  sin.sizes() == cos.sizes() && cos.size(0) >= T && cos.size(1) == D / 2,
+              "rope: cos / sin must be float32 [>= T, D/2] tables");
+  const c10::DeviceGuard guard(qkv.device());
+  at::Tensor out = in_place ? qkv : at::empty_like(qkv);
+  pda::rope_apply(dt, qkv.data_ptr(), out.data_ptr(), cos.data_ptr<float>(), sin.data_ptr<float>(), (int)B, (int)T,
+                  (int)num_heads, (int)D, inverse, current_stream());
+  check_launch("rope_apply");
+  return out;
+}
+
 // ---------------------------------------------------------------- weight grad --
 bool wgrad_supported(int64_t M, int64_t I, int64_t J) { return pda::wgrad_supported((int)M, (int)I, (int)J); }
 
@@ -392,6 +416,8 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
 }  // namespace
 
 void bind_ops(py::module_& m) {
+  m.def("rope_apply", &rope_apply, py::arg("qkv"), py::arg("cos"), py::arg("sin"), py::arg("num_heads"),
+        py::arg("inverse"), py::arg("in_place"));
   m.def("wgrad_supported", &wgrad_supported);
   m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"),
         py::arg("out") = py::none(), py::arg("accumulate") = false);

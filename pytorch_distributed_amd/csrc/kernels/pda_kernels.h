@@ -100,6 +100,14 @@ void attention_backward(const void* qkv, const void* out, const void* dout, cons
 // keep[B*H][T][T] (bytes): 1 where the dropout mask of (dropout_p, seed) keeps the probability.
 void attention_dropout_mask(uint8_t* keep, int B, int T, int H, float dropout_p, uint64_t seed, hipStream_t stream);
 
+// ------------------------------------------------------------------- Rotary --
+// Rotates the Q and K thirds of a packed [B, T, 3, H, D] activation (rotate-half pairing) by
+// the angles of the fp32 tables cos / sin [>= T, D/2]; `inverse` rotates back (the backward).
+// src == dst works in place; otherwise the V third is copied through. D/2 must be a multiple of
+// the 16-byte vector width (8 bf16 / 4 fp32).
+void rope_apply(DType dtype, const void* src, void* dst, const float* cos_tab, const float* sin_tab, int B, int T,
+                int H, int D, bool inverse, hipStream_t stream);
+
 // ------------------------------------------------------------- Weight gradient --
 // C[I, J] = A[M, I]^T . B[M, J] (bf16 operands, row strides lda / ldb in elements) with the
 // contraction M split over S slices: fp32 partials [S][I][J] (+ optional column sums of A,

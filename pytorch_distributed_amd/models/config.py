@@ -67,6 +67,10 @@ class LlamaConfig:
     def to_dict(self) -> Dict[str, Any]:
         return asdict(self)
 
+    def without_dropout(self) -> "LlamaConfig":
+        """Llama-style models have no dropout; present so callers can treat both families alike."""
+        return self
+
 
 _GPT2 = {
     "gpt2": dict(n_layer=12, n_head=12, n_embd=768),

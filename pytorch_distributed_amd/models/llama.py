@@ -18,7 +18,7 @@ import torch
 from torch import nn
 from torch.utils.checkpoint import checkpoint
 
-from .. import ops
+from .. import _ext, ops
 from .config import LlamaConfig, get_config
 
 
@@ -49,6 +49,13 @@ def _rotate(x, cos, sin, inverse: bool):
     return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1).to(x.dtype)
 
 
+def _native_rope_ok(qkv, cos, head_dim: int) -> bool:
+    vec = 8 if qkv.dtype == torch.bfloat16 else 4
+    return (_ext.use_hip(qkv) and qkv.dtype in (torch.bfloat16, torch.float32) and qkv.is_contiguous()
+            and cos.dtype == torch.float32 and cos.is_cuda and cos.is_contiguous()
+            and head_dim % 2 == 0 and (head_dim // 2) % vec == 0)
+
+
 class _RopePacked(torch.autograd.Function):
     """Rotary embedding applied to the Q and K thirds of a packed [B, T, 3, H, D] activation."""
 
@@ -56,17 +63,24 @@ class _RopePacked(torch.autograd.Function):
     def forward(ctx, qkv, cos, sin, num_heads):
         B, T, W = qkv.shape
         D = W // (3 * num_heads)
+        ctx.save_for_backward(cos, sin)
+        ctx.num_heads = num_heads
+        ctx.native = _native_rope_ok(qkv, cos, D)
+        if ctx.native:
+            # one streaming HIP kernel, in place on the projection output (nothing else reads it)
+            ctx.mark_dirty(qkv)
+            return _ext.require().rope_apply(qkv, cos, sin, num_heads, False, True)
         v = qkv.view(B, T, 3, num_heads, D)
         out = torch.empty_like(v)
         out[:, :, :2] = _rotate(v[:, :, :2], cos[:T], sin[:T], inverse=False)
         out[:, :, 2] = v[:, :, 2]
-        ctx.save_for_backward(cos, sin)
-        ctx.num_heads = num_heads
         return out.view(B, T, W)
 
     @staticmethod
     def backward(ctx, dout):
         cos, sin = ctx.saved_tensors
+        if ctx.native:
+            return _ext.require().rope_apply(dout.contiguous(), cos, sin, ctx.num_heads, True, False), None, None, None
         B, T, W = dout.shape
         D = W // (3 * ctx.num_heads)
         g = dout.reshape(B, T, 3, ctx.num_heads, D)

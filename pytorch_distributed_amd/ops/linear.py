@@ -68,8 +68,11 @@ class _LinearFn(torch.autograd.Function):
         # weight with a callable returning (slice_of_flat_buffer, accumulate).
         ctx.grad_sink = getattr(weight, "_pda_grad_sink", None)
         x2 = x.reshape(-1, x.shape[-1])
-        y = planned_mm(x2, weight, trans_b=True, bias=bias)
-        return y.view(*x.shape[:-1], weight.shape[0])
+        # The result is allocated in its final shape (not returned as a view of a 2-D tensor), so
+        # a following op may legally work on it in place (the rotary kernel does).
+        y = torch.empty(*x.shape[:-1], weight.shape[0], dtype=x.dtype, device=x.device)
+        planned_mm(x2, weight, trans_b=True, bias=bias, out=y.view(-1, weight.shape[0]))
+        return y
 
     @staticmethod
     def backward(ctx, dy):

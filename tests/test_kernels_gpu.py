@@ -307,3 +307,30 @@ def test_attention_dropout_follows_torch_seed():
     torch.manual_seed(3)
     c = ops.causal_attention(qkv, 2, dropout_p=0.2, training=True)
     assert torch.equal(a, c) and not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float32, 64)])
+def test_rope_kernel_matches_reference(dtype, D):
+    """In-place rotary kernel on the packed QKV activation, forward and backward, against the
+    PyTorch rotate-half formula in fp32."""
+    _ext_loaded()
+    from pytorch_distributed_amd.models.llama import _RopePacked, _rotate, rope_tables
+
+    torch.manual_seed(11)
+    B, T, H = 2, 96, 3
+    cos, sin = rope_tables(128, D, 10000.0, DEV)
+    base = torch.randn(B, T, 3 * H * D, device=DEV, dtype=dtype)
+    dout = torch.randn(B, T, 3 * H * D, device=DEV, dtype=dtype)
+    x = base.clone().requires_grad_(True)
+    out = _RopePacked.apply(x * 1.0, cos, sin, H)  # x * 1.0: a non-leaf the op may rotate in place
+    out.backward(dout)
+    v = base.float().view(B, T, 3, H, D)
+    ref = v.clone()
+    ref[:, :, :2] = _rotate(v[:, :, :2], cos[:T], sin[:T], inverse=False)
+    g = dout.float().view(B, T, 3, H, D)
+    gref = g.clone()
+    gref[:, :, :2] = _rotate(g[:, :, :2], cos[:T], sin[:T], inverse=True)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_err(out, ref.view(B, T, -1)) < tol
+    assert rel_err(x.grad, gref.view(B, T, -1)) < tol
+    assert torch.equal(out.view(B, T, 3, H, D)[:, :, 2], base.view(B, T, 3, H, D)[:, :, 2])
