@@ -56,6 +56,10 @@ class DDP(nn.Module):
             if params[0].device != want:
                 raise ValueError(f"DDP: module lives on {params[0].device}, device_ids says {want}")
         self._params = params
+        if params[0].is_cuda and dist.get_backend(self.process_group) == "gloo":
+            # gloo's device-tensor all-reduce stalls intermittently under the reducer's overlapped
+            # launches (measured with two ranks on one GPU); GPU tensors go over RCCL.
+            raise RuntimeError("DDP on GPU tensors needs the 'nccl' (RCCL) backend, not gloo")
 
         # Same shapes everywhere, then rank 0's values everywhere (parameters and buffers).
         comm.assert_same_across_ranks([p.numel() for p in params], "parameter sizes", self.process_group)

@@ -68,6 +68,12 @@ class FSDP(nn.Module):
         self.rank = dist.get_rank(self.process_group)
         self.forward_prefetch = forward_prefetch
         self.backward_prefetch = backward_prefetch
+        first = next((p for p in module.parameters() if p.requires_grad), None)
+        if first is not None and first.is_cuda and dist.get_backend(self.process_group) == "gloo":
+            # gloo's device-tensor collectives pin the buffers they were given on streams of their
+            # own; with the units' release-and-reallocate storage a second backward stalls in them
+            # (measured). GPU tensors go over RCCL.
+            raise RuntimeError("FSDP on GPU tensors needs the 'nccl' (RCCL) backend, not gloo")
 
         # Parameters already owned by nested FSDP instances stay with them.
         nested = [m for m in module.modules() if isinstance(m, FSDP)]
