@@ -37,12 +37,12 @@ constexpr int kWaves = 4;
 constexpr int kBM = 128;  // queries per workgroup
 constexpr int kBN = 64;   // keys per tile
 
-// amdgpu_waves_per_eu(3) for D = 64: a register budget of 170 per wave keeps the MFMA
+// amdgpu_waves_per_eu (3 for D = 64, 2 for D = 128): a register budget of 170 / 256 per wave keeps the MFMA
 // accumulators in ordinary VGPRs (with the launch-bounds default of 512 the compiler parks
 // them in AGPRs and copies every score across for the softmax) and lets three workgroups
 // share a CU.
 template <int D, bool kDrop>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? (kDrop ? 2 : 3) : 1))) void attn_fwd_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? (kDrop ? 2 : 3) : 2))) void attn_fwd_kernel(
     const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, float* __restrict__ lse_out, int B, int T, int H,
     float scale, DropoutParams drop) {
   constexpr int kKSteps = D / 16;   // k-steps of the S^T product
