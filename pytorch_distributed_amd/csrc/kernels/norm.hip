@@ -133,18 +133,39 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
     if (vi < nvec) VecIO<T>::load(w + vi * kVec, wv[it]);
   }
 
+  // The row loop is software-pipelined: the loads of the wave's NEXT row are issued before the
+  // two reductions of the current one, so each wave keeps two rows of dy / x / dresidual in
+  // flight (the grid is capped by the number of partial rows, i.e. only ~2 waves per SIMD, and a
+  // load -> reduce -> store chain per row left the memory system idle half of the time).
+  typedef typename VecIO<T>::Raw Raw;
+  Raw dy_raw[kMaxIt], x_raw[kMaxIt], res_raw[kHasRes ? kMaxIt : 1];
+  float mean = 0.f, rstd = 0.f;
+  auto fetch = [&](int64_t row, Raw (&dyr)[kMaxIt], Raw (&xr)[kMaxIt], Raw (&rr)[kHasRes ? kMaxIt : 1], float& m,
+                   float& rs) {
+    m = kRms ? 0.f : mean_in[row];
+    rs = rstd_in[row];
+#pragma unroll
+    for (int it = 0; it < kMaxIt; ++it) {
+      const int vi = lane + it * 64;
+      if (vi < nvec) {
+        dyr[it] = VecIO<T>::load_raw(dy + row * d + vi * kVec);
+        xr[it] = VecIO<T>::load_raw(x + row * d + vi * kVec);
+        if (kHasRes) rr[it] = VecIO<T>::load_raw(dres + row * d + vi * kVec);
+      }
+    }
+  };
+  if (wave_global < rows) fetch(wave_global, dy_raw, x_raw, res_raw, mean, rstd);
   for (int64_t row = wave_global; row < rows; row += wave_stride) {
-    const float mean = kRms ? 0.f : mean_in[row];
-    const float rstd = rstd_in[row];
-    typename VecIO<T>::Raw dy_raw[kMaxIt], x_raw[kMaxIt];  // kept packed between the passes
+    Raw dy_nxt[kMaxIt], x_nxt[kMaxIt], res_nxt[kHasRes ? kMaxIt : 1];
+    float mean_nxt = 0.f, rstd_nxt = 0.f;
+    const bool has_next = row + wave_stride < rows;  // wave-uniform
+    if (has_next) fetch(row + wave_stride, dy_nxt, x_nxt, res_nxt, mean_nxt, rstd_nxt);
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int it = 0; it < kMaxIt; ++it) {
       const int vi = lane + it * 64;
       if (vi < nvec) {
         float dyv[kVec], xv[kVec];
-        dy_raw[it] = VecIO<T>::load_raw(dy + row * d + vi * kVec);
-        x_raw[it] = VecIO<T>::load_raw(x + row * d + vi * kVec);
         VecIO<T>::unpack(dy_raw[it], dyv);
         VecIO<T>::unpack(x_raw[it], xv);
 #pragma unroll
@@ -174,12 +195,22 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
         }
         if (kHasRes) {
           float r[kVec];
-          VecIO<T>::load(dres + row * d + vi * kVec, r);
+          VecIO<T>::unpack(res_raw[it], r);
 #pragma unroll
           for (int k = 0; k < kVec; ++k) o[k] += r[k];
         }
         VecIO<T>::store(dx + row * d + vi * kVec, o);
       }
+    }
+    if (has_next) {
+#pragma unroll
+      for (int it = 0; it < kMaxIt; ++it) {
+        dy_raw[it] = dy_nxt[it];
+        x_raw[it] = x_nxt[it];
+        if (kHasRes) res_raw[it] = res_nxt[it];
+      }
+      mean = mean_nxt;
+      rstd = rstd_nxt;
     }
   }
 
