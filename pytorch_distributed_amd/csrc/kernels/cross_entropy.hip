@@ -27,7 +27,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 // (rows longer than the register budget). kScalar: unaligned rows, one
 // element per access (always re-reads).
 template <typename T, int kMaxIt, bool kScalar>
-__global__ __launch_bounds__(kThreads) void ce_kernel(T* __restrict__ logits,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kMaxIt <= 16 ? 4 : 2))) void ce_kernel(T* __restrict__ logits,
                                                       const int64_t* __restrict__ targets,
                                                       float* __restrict__ row_loss,
                                                       const float* __restrict__ grad_scale,
