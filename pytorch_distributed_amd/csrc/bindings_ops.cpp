@@ -402,13 +402,11 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
     TORCH_CHECK(!accumulate, "wgrad: accumulate needs an out tensor");
     dw = at::empty({I, J}, dy.options());
   }
-  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, dw.scalar_type() == at::kFloat ? pda::kF32 : pda::kBF16,
-                    dw.data_ptr(), accumulate, stream);
   at::Tensor db;
-  if (want_bias) {
-    db = at::empty({I}, dy.options());
-    pda::wgrad_reduce(bpartial.data_ptr<float>(), S, I, pda::kBF16, db.data_ptr(), false, stream);
-  }
+  if (want_bias) db = at::empty({I}, dy.options());
+  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, dw.scalar_type() == at::kFloat ? pda::kF32 : pda::kBF16,
+                    dw.data_ptr(), accumulate, want_bias ? bpartial.data_ptr<float>() : nullptr, I,
+                    want_bias ? db.data_ptr() : nullptr, stream);
   check_launch("wgrad_reduce");
   return {dw, db};
 }

@@ -309,12 +309,27 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
   }
 }
 
-// out[n] (+)= sum_s partial[s][n], n over `numel` elements, 4 per thread.
-template <typename OutT>
+// out[n] (+)= sum_s partial[s][n], n over `numel` elements, 4 per thread. The last
+// `bias_blocks` workgroups of the grid do the same for the (much smaller) bias partials, so a
+// linear layer's weight and bias gradients are folded by one launch.
+template <typename OutT, typename BiasT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S,
                                                            int64_t numel, OutT* __restrict__ out,
-                                                           bool accumulate) {
-  const int64_t stride = int64_t(gridDim.x) * 256 * 4;
+                                                           bool accumulate, const float* __restrict__ bias_partial,
+                                                           int64_t bias_numel, BiasT* __restrict__ bias_out,
+                                                           int bias_blocks) {
+  const int main_blocks = int(gridDim.x) - bias_blocks;
+  if (int(blockIdx.x) >= main_blocks) {
+    const int64_t stride = int64_t(bias_blocks) * 256 * 4;
+    for (int64_t n = (int64_t(int(blockIdx.x) - main_blocks) * 256 + threadIdx.x) * 4; n < bias_numel; n += stride) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(bias_partial + n);
+      for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(bias_partial + int64_t(k) * bias_numel + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) VecIO<BiasT>::store1(bias_out + n + e, s[e]);
+    }
+    return;
+  }
+  const int64_t stride = int64_t(main_blocks) * 256 * 4;
   for (int64_t n = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 4; n < numel; n += stride) {
     f32x4 s = *reinterpret_cast<const f32x4*>(partial + n);
     for (int k = 1; k < S; ++k) {
@@ -371,15 +386,18 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
 }
 
 void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
-                  hipStream_t stream) {
+                  const float* bias_partial, int64_t bias_numel, void* bias_out, hipStream_t stream) {
   int64_t blocks = ceil_div(numel, 1024);
   if (blocks > 2048) blocks = 2048;
+  const int bias_blocks = bias_partial != nullptr ? (int)(ceil_div(bias_numel, 1024) < 8 ? ceil_div(bias_numel, 1024) : 8) : 0;
+  const dim3 grid((unsigned)(blocks + bias_blocks));
+  // the bias gradient has the dtype of the activations (bf16)
   if (out_dtype == kBF16)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<bf16_raw>, dim3((unsigned)blocks), dim3(256), 0, stream, partial, S,
-                       numel, (bf16_raw*)out, accumulate);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_raw, bf16_raw>), grid, dim3(256), 0, stream, partial, S, numel,
+                       (bf16_raw*)out, accumulate, bias_partial, bias_numel, (bf16_raw*)bias_out, bias_blocks);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, partial, S,
-                       numel, (float*)out, accumulate);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<float, bf16_raw>), grid, dim3(256), 0, stream, partial, S, numel,
+                       (float*)out, accumulate, bias_partial, bias_numel, (bf16_raw*)bias_out, bias_blocks);
 }
 
 }  // namespace pda

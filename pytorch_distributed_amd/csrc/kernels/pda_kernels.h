@@ -118,8 +118,9 @@ bool wgrad_supported(int M, int I, int J);
 int wgrad_pick_slices(int M, int I, int J);
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream);
+// bias_partial (optional, [S][bias_numel]) is folded into bias_out (bf16) by the same launch.
 void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
-                  hipStream_t stream);
+                  const float* bias_partial, int64_t bias_numel, void* bias_out, hipStream_t stream);
 
 // ----------------------------------------------------------------- Utilities --
 // dst(fp32) += src(bf16) * scale, and plain casts, for main-grad accumulation.
