@@ -342,6 +342,26 @@ at::Tensor attention_dropout_mask(int64_t B, int64_t H, int64_t T, double dropou
 }
 
 // ------------------------------------------------------------------- rotary --
+// [rows, cols] bf16 (unit column stride, any 8-aligned row pitch) -> [cols, rows_padded], rows_padded
+// = rows rounded up to pad_rows_to, with the padding columns zero.
+at::Tensor transpose_2d(const at::Tensor& src, int64_t pad_rows_to) {
+  TORCH_CHECK(src.defined() && src.is_cuda() && src.dim() == 2, "transpose_2d: expected a 2-D GPU tensor");
+  TORCH_CHECK(src.scalar_type() == at::kBFloat16, "transpose_2d: bf16 only");
+  const int64_t rows = src.size(0), cols = src.size(1);
+  TORCH_CHECK(rows > 0 && cols > 0 && rows < (int64_t(1) << 30) && cols < (int64_t(1) << 30), "transpose_2d: bad shape");
+  TORCH_CHECK(src.stride(1) == 1 && src.stride(0) >= cols && src.stride(0) % 8 == 0 && cols % 8 == 0,
+              "transpose_2d: rows must be contiguous, 16-byte aligned and a multiple of 8 long");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(src.data_ptr()) % 16 == 0, "transpose_2d: source must be 16-byte aligned");
+  TORCH_CHECK(pad_rows_to >= 8 && pad_rows_to % 8 == 0, "transpose_2d: pad_rows_to must be a multiple of 8");
+  const c10::DeviceGuard guard(src.device());
+  const int64_t rows_padded = (rows + pad_rows_to - 1) / pad_rows_to * pad_rows_to;
+  at::Tensor out = at::empty({cols, rows_padded}, src.options());
+  pda::transpose_bf16(src.data_ptr(), src.stride(0), out.data_ptr(), rows_padded, (int)rows, (int)cols,
+                      (int)rows_padded, current_stream());
+  check_launch("transpose_2d");
+  return out;
+}
+
 at::Tensor rope_apply(const at::Tensor& qkv, const at::Tensor& cos, const at::Tensor& sin, int64_t num_heads,
                       bool inverse, bool in_place) {
   check_gpu(qkv, "qkv");
@@ -416,6 +436,7 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
 void bind_ops(py::module_& m) {
   m.def("rope_apply", &rope_apply, py::arg("qkv"), py::arg("cos"), py::arg("sin"), py::arg("num_heads"),
         py::arg("inverse"), py::arg("in_place"));
+  m.def("transpose_2d", &transpose_2d, py::arg("src"), py::arg("pad_rows_to") = 8);
   m.def("wgrad_supported", &wgrad_supported);
   m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"),
         py::arg("out") = py::none(), py::arg("accumulate") = false);

@@ -108,6 +108,13 @@ void attention_dropout_mask(uint8_t* keep, int B, int T, int H, float dropout_p,
 void rope_apply(DType dtype, const void* src, void* dst, const float* cos_tab, const float* sin_tab, int B, int T,
                 int H, int D, bool inverse, hipStream_t stream);
 
+// ------------------------------------------------------------------- Transpose --
+// dst[c][r] = src[r][c] for a bf16 [rows, cols] matrix (cols % 8 == 0, row pitches in elements,
+// multiples of 8). Rows rows..rows_padded-1 of the source are taken as zeros, i.e. every
+// destination row is written up to column rows_padded (a multiple of 8, <= ld_dst).
+void transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, int rows_padded,
+                    hipStream_t stream);
+
 // ------------------------------------------------------------- Weight gradient --
 // C[I, J] = A[M, I]^T . B[M, J] (bf16 operands, row strides lda / ldb in elements) with the
 // contraction M split over S slices: fp32 partials [S][I][J] (+ optional column sums of A,

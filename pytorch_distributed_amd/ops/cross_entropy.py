@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _ext
-from .linear import planned_mm
+from .linear import input_grad_mm, planned_mm
 
 _PAD = 128
 
@@ -93,7 +93,7 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
         dlogits = dlogits_p[:, :V]
         dhidden = dweight = None
         if ctx.needs_input_grad[0]:
-            dhidden = planned_mm(dlogits, weight).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
+            dhidden = input_grad_mm(dlogits, weight, dlogits_p).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
         if ctx.needs_input_grad[1]:
             dweight = torch.mm(dlogits.t(), h2).mul_(dloss.to(weight.dtype))
         return dhidden, dweight, None, None

@@ -12,6 +12,12 @@ weight gradient.
   (split-K over tokens, transposed LDS operand reads), which also returns the bias gradient
   as a by-product instead of a separate reduction pass over ``dY``.
 
+* The input gradient ``dx = dy W`` contracts over the ROW index of ``W [out, in]``; the library's
+  kernels for that layout are 5-15 % slower than the ones for two contraction-contiguous
+  operands, and transposing a weight (``csrc/kernels/transpose.hip``) costs microseconds against a
+  GEMM of hundreds. ``input_grad_mm`` therefore times both routes the first time a shape is seen
+  and keeps the faster one (``PDA_NO_DGRAD_TRANSPOSE=1`` pins the direct layout).
+
 Shapes the native paths do not cover (non-bf16, dimensions that are not multiples of 8, token
 counts that are not multiples of 32) and CPU tensors use ``torch`` matmuls.
 ``PDA_NO_NATIVE_WGRAD=1`` / ``PDA_NO_GEMM_PLANNER=1`` switch the two native paths off
@@ -59,6 +65,52 @@ def planned_mm(a: torch.Tensor, b: torch.Tensor, *, trans_b: bool = False, bias=
     return torch.mm(a, bm, out=out) if out is not None else torch.mm(a, bm)
 
 
+# (tokens, out, in) -> True when "transpose the weight, then the contraction-contiguous GEMM" beat
+# the direct layout on this device.
+_DGRAD_TRANSPOSED: dict = {}
+_DGRAD_MIN_TOKENS = 2048
+
+
+def _time_us(fn, runs: int = 3) -> float:
+    fn()
+    fn()  # the first call plans the GEMM, the second warms the chosen kernel
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(runs):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) * 1e3 / runs
+
+
+def input_grad_mm(dy2: torch.Tensor, weight: torch.Tensor, dy_padded: torch.Tensor = None) -> torch.Tensor:
+    """``dy2 @ weight`` for ``dy2 [M, N]`` and ``weight [N, K]`` (the input gradient of a linear layer).
+
+    ``dy_padded`` is ``dy2`` including zero-valued padding columns up to its row pitch (the LM
+    head's logits gradient, N = 50257 padded to 50304); with it the transposed route contracts
+    over the padded, aligned length against a zero-padded transposed weight."""
+    M, N = dy2.shape
+    K = weight.shape[1]
+    direct = lambda: planned_mm(dy2, weight)  # noqa: E731
+    if (M < _DGRAD_MIN_TOKENS or K % 8 != 0 or not _planner_ok(dy2, weight)
+            or os.environ.get("PDA_NO_DGRAD_TRANSPOSE") == "1"):
+        return direct()
+    a = dy2 if dy_padded is None else dy_padded
+    pad_to = 8 if dy_padded is None else a.shape[1]  # transposed weight rows: N rounded up to this
+    if pad_to % 8 != 0 or a.shape[0] != M or a.shape[1] != -(-N // pad_to) * pad_to or not _planner_ok(a):
+        return direct()
+    ext = _ext.require()
+    transposed = lambda: planned_mm(a, ext.transpose_2d(weight, pad_to), trans_b=True)  # noqa: E731
+    key = (weight.device.index, M, N, K)
+    choice = _DGRAD_TRANSPOSED.get(key)
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing():
+            return direct()  # cannot time inside a graph capture; decided by an eager step
+        choice = _time_us(transposed) < _time_us(direct)
+        _DGRAD_TRANSPOSED[key] = choice
+    return transposed() if choice else direct()
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -81,7 +133,7 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = planned_mm(dy2, weight).view(x.shape)
+            dx = input_grad_mm(dy2, weight).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if need_w and _native_wgrad_ok(dy2, x2):
             if not dy2.is_contiguous():

@@ -334,3 +334,43 @@ def test_rope_kernel_matches_reference(dtype, D):
     assert rel_err(out, ref.view(B, T, -1)) < tol
     assert rel_err(x.grad, gref.view(B, T, -1)) < tol
     assert torch.equal(out.view(B, T, 3, H, D)[:, :, 2], base.view(B, T, 3, H, D)[:, :, 2])
+
+
+@pytest.mark.parametrize("rows,cols,pad", [(1280, 5120, 8), (3840, 1280, 8), (50257, 1280, 50304), (72, 264, 8), (100, 64, 128)])
+def test_transpose_kernel(rows, cols, pad):
+    ext = _ext.require()
+    src = torch.randn(rows, cols, device=DEV, dtype=torch.bfloat16)
+    out = ext.transpose_2d(src, pad)
+    rp = -(-rows // pad) * pad
+    assert out.shape == (cols, rp)
+    assert torch.equal(out[:, :rows], src.t())
+    assert not out[:, rows:].any()
+    view = torch.randn(rows, cols + 16, device=DEV, dtype=torch.bfloat16)[:, 8:8 + cols]  # pitched source
+    if view.data_ptr() % 16 == 0:
+        assert torch.equal(ext.transpose_2d(view, pad)[:, :rows], view.t())
+
+
+def test_input_grad_layout_choice_matches_direct(monkeypatch):
+    """Whichever route the timing picks, the input gradient equals the direct product (the two
+    routes run the same contraction; only the operand layout differs)."""
+    import importlib
+
+    L = importlib.import_module("pytorch_distributed_amd.ops.linear")
+
+    dy = torch.randn(4096, 3840, device=DEV, dtype=torch.bfloat16)
+    w = torch.randn(3840, 1280, device=DEV, dtype=torch.bfloat16) * 0.02
+    ref = (dy.float() @ w.float())
+    got = L.input_grad_mm(dy, w)
+    assert (dy.device.index, 4096, 3840, 1280) in L._DGRAD_TRANSPOSED
+    assert rel_err(got, ref) < 1e-2
+    for forced in (True, False):
+        monkeypatch.setitem(L._DGRAD_TRANSPOSED, (dy.device.index, 4096, 3840, 1280), forced)
+        assert rel_err(L.input_grad_mm(dy, w), ref) < 1e-2
+    # padded route (LM head): N = 1001 valid columns in a 1024-column buffer whose padding is zero
+    buf = torch.zeros(4096, 1024, device=DEV, dtype=torch.bfloat16)
+    buf[:, :1001] = torch.randn(4096, 1001, device=DEV, dtype=torch.bfloat16)
+    w2 = torch.randn(1001, 768, device=DEV, dtype=torch.bfloat16) * 0.02
+    ref2 = buf[:, :1001].float() @ w2.float()
+    for forced in (True, False):
+        monkeypatch.setitem(L._DGRAD_TRANSPOSED, (dy.device.index, 4096, 1001, 768), forced)
+        assert rel_err(L.input_grad_mm(buf[:, :1001], w2, buf), ref2) < 1e-2
