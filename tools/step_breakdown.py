@@ -38,6 +38,19 @@ def main():
     print(f"per step over the last {steps} steps: wall {wall:.2f} ms, kernel time {sum(tot.values()):.2f} ms")
     for k, v in tot.most_common():
         print(f"{v:8.2f} ms {cnt[k] / steps:7.1f} launches  {k}")
+    # Per hardware queue: busy time and the largest idle gaps (a stalled compute stream shows here).
+    queues = collections.defaultdict(list)
+    for r in sel:
+        queues[(r.get("Queue_Id"), r.get("Stream_Id"))].append(r)
+    for q, rs in sorted(queues.items(), key=lambda kv: -len(kv[1])):
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / 1e6 / steps
+        gaps = sorted(((int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3, a["Kernel_Name"][:48], b["Kernel_Name"][:48])
+                      for a, b in zip(rs, rs[1:]))
+        big = [g for g in gaps if g[0] > 20]
+        print(f"queue {q}: {len(rs) / steps:.0f} launches, busy {busy:.2f} ms per step, "
+              f"{len(big) / steps:.0f} gaps > 20 us totalling {sum(g[0] for g in big) / 1e3 / steps:.2f} ms per step")
+        for g in gaps[-5:][::-1]:
+            print(f"      {g[0]:9.1f} us between {g[1]} -> {g[2]}")
 
 
 if __name__ == "__main__":
