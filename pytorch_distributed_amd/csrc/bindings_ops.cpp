@@ -84,7 +84,8 @@ std::vector<at::Tensor> norm_forward(const at::Tensor& x, const std::optional<at
 std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
                                       const at::Tensor& weight, const std::optional<at::Tensor>& mean,
                                       const at::Tensor& rstd, const std::optional<at::Tensor>& dresidual,
-                                      bool rms) {
+                                      bool rms, const std::optional<at::Tensor>& dweight_out, bool accumulate_w,
+                                      const std::optional<at::Tensor>& dbias_out, bool accumulate_b) {
   check_gpu(dy, "dy");
   check_gpu(x, "x");
   check_gpu(weight, "weight");
@@ -122,10 +123,23 @@ std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
                      rstd.data_ptr<float>(), dres_ptr, dx.data_ptr(), dwp.data_ptr<float>(),
                      rms ? nullptr : dbp.data_ptr<float>(), rows, (int)d, stream);
   check_launch("norm_backward");
-  at::Tensor dw = at::empty_like(weight);
-  at::Tensor db = rms ? at::Tensor() : at::empty_like(weight);
+  // Parameter gradients go into fresh tensors, or (written / accumulated) into the tensors the
+  // caller supplies: slices of a reducer's flat gradient buffer, or existing .grad tensors.
+  auto sink = [&](const std::optional<at::Tensor>& out, bool accumulate, const char* what) {
+    if (!out.has_value() || !out->defined()) {
+      TORCH_CHECK(!accumulate, "norm: accumulate needs ", what);
+      return at::empty_like(weight);
+    }
+    TORCH_CHECK(out->is_cuda() && out->is_contiguous() && out->numel() == d &&
+                    (out->scalar_type() == at::kBFloat16 || out->scalar_type() == at::kFloat),
+                "norm: ", what, " must be a contiguous bf16/fp32 GPU tensor with ", d, " elements");
+    return *out;
+  };
+  at::Tensor dw = sink(dweight_out, accumulate_w, "dweight_out");
+  at::Tensor db = rms ? at::Tensor() : sink(dbias_out, accumulate_b, "dbias_out");
   pda::norm_reduce_partials(dwp.data_ptr<float>(), rms ? nullptr : dbp.data_ptr<float>(), prow, (int)d,
-                            dt, dw.data_ptr(), rms ? nullptr : db.data_ptr(), false, stream);
+                            dtype_of(dw), dw.data_ptr(), accumulate_w, rms ? pda::kF32 : dtype_of(db),
+                            rms ? nullptr : db.data_ptr(), accumulate_b, stream);
   check_launch("norm_reduce_partials");
   return {dx, dw, db};
 }
@@ -392,7 +406,8 @@ bool wgrad_supported(int64_t M, int64_t I, int64_t J) { return pda::wgrad_suppor
 // With `out` the weight gradient is written into that tensor (a slice of a reducer's flat
 // gradient buffer) instead of a fresh one — added to its contents when `accumulate` is set.
 std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, bool want_bias,
-                                     const std::optional<at::Tensor>& out, bool accumulate) {
+                                     const std::optional<at::Tensor>& out, bool accumulate,
+                                     const std::optional<at::Tensor>& bias_out, bool bias_accumulate) {
   TORCH_CHECK(dy.is_cuda() && x.is_cuda() && dy.dim() == 2 && x.dim() == 2, "wgrad: 2-D GPU tensors");
   TORCH_CHECK(dy.scalar_type() == at::kBFloat16 && x.scalar_type() == at::kBFloat16, "wgrad: bf16 only");
   TORCH_CHECK(dy.stride(1) == 1 && x.stride(1) == 1, "wgrad: rows must be contiguous");
@@ -423,10 +438,20 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
     dw = at::empty({I, J}, dy.options());
   }
   at::Tensor db;
-  if (want_bias) db = at::empty({I}, dy.options());
-  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, dw.scalar_type() == at::kFloat ? pda::kF32 : pda::kBF16,
-                    dw.data_ptr(), accumulate, want_bias ? bpartial.data_ptr<float>() : nullptr, I,
-                    want_bias ? db.data_ptr() : nullptr, stream);
+  if (want_bias) {
+    if (bias_out.has_value() && bias_out->defined()) {
+      db = *bias_out;
+      TORCH_CHECK(db.is_cuda() && db.is_contiguous() && db.numel() == I &&
+                      (db.scalar_type() == at::kBFloat16 || db.scalar_type() == at::kFloat),
+                  "wgrad: bias_out must be a contiguous bf16/fp32 GPU tensor with ", I, " elements");
+    } else {
+      TORCH_CHECK(!bias_accumulate, "wgrad: bias_accumulate needs a bias_out tensor");
+      db = at::empty({I}, dy.options());
+    }
+  }
+  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, dtype_of(dw), dw.data_ptr(), accumulate,
+                    want_bias ? bpartial.data_ptr<float>() : nullptr, I, want_bias ? dtype_of(db) : pda::kBF16,
+                    want_bias ? db.data_ptr() : nullptr, want_bias && bias_accumulate, stream);
   check_launch("wgrad_reduce");
   return {dw, db};
 }
@@ -439,11 +464,13 @@ void bind_ops(py::module_& m) {
   m.def("transpose_2d", &transpose_2d, py::arg("src"), py::arg("pad_rows_to") = 8);
   m.def("wgrad_supported", &wgrad_supported);
   m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"),
-        py::arg("out") = py::none(), py::arg("accumulate") = false);
+        py::arg("out") = py::none(), py::arg("accumulate") = false, py::arg("bias_out") = py::none(),
+        py::arg("bias_accumulate") = false);
   m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
         py::arg("bias"), py::arg("eps"), py::arg("rms"));
-  m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"),
-        py::arg("mean"), py::arg("rstd"), py::arg("dresidual"), py::arg("rms"));
+  m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"),
+        py::arg("rstd"), py::arg("dresidual"), py::arg("rms"), py::arg("dweight_out") = py::none(),
+        py::arg("accumulate_w") = false, py::arg("dbias_out") = py::none(), py::arg("accumulate_b") = false);
   m.def("gelu_forward", &gelu_forward);
   m.def("gelu_backward", &gelu_backward);
   m.def("swiglu_forward", &swiglu_forward);

@@ -311,13 +311,14 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
 
 // out[n] (+)= sum_s partial[s][n], n over `numel` elements, 4 per thread. The last
 // `bias_blocks` workgroups of the grid do the same for the (much smaller) bias partials, so a
-// linear layer's weight and bias gradients are folded by one launch.
+// linear layer's weight and bias gradients are folded by one launch (each written or added
+// to its destination, which may be a slice of a reducer's flat gradient buffer).
 template <typename OutT, typename BiasT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S,
                                                            int64_t numel, OutT* __restrict__ out,
                                                            bool accumulate, const float* __restrict__ bias_partial,
                                                            int64_t bias_numel, BiasT* __restrict__ bias_out,
-                                                           int bias_blocks) {
+                                                           bool bias_accumulate, int bias_blocks) {
   const int main_blocks = int(gridDim.x) - bias_blocks;
   if (int(blockIdx.x) >= main_blocks) {
     const int64_t stride = int64_t(bias_blocks) * 256 * 4;
@@ -325,7 +326,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       f32x4 s = *reinterpret_cast<const f32x4*>(bias_partial + n);
       for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(bias_partial + int64_t(k) * bias_numel + n);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) VecIO<BiasT>::store1(bias_out + n + e, s[e]);
+      for (int e = 0; e < 4; ++e) {
+        float v = s[e];
+        if (bias_accumulate) v += VecIO<BiasT>::load1(bias_out + n + e);
+        VecIO<BiasT>::store1(bias_out + n + e, v);
+      }
     }
     return;
   }
@@ -386,18 +391,22 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
 }
 
 void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
-                  const float* bias_partial, int64_t bias_numel, void* bias_out, hipStream_t stream) {
+                  const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
+                  bool bias_accumulate, hipStream_t stream) {
   int64_t blocks = ceil_div(numel, 1024);
   if (blocks > 2048) blocks = 2048;
   const int bias_blocks = bias_partial != nullptr ? (int)(ceil_div(bias_numel, 1024) < 8 ? ceil_div(bias_numel, 1024) : 8) : 0;
   const dim3 grid((unsigned)(blocks + bias_blocks));
-  // the bias gradient has the dtype of the activations (bf16)
-  if (out_dtype == kBF16)
-    hipLaunchKernelGGL((wgrad_reduce_kernel<bf16_raw, bf16_raw>), grid, dim3(256), 0, stream, partial, S, numel,
-                       (bf16_raw*)out, accumulate, bias_partial, bias_numel, (bf16_raw*)bias_out, bias_blocks);
-  else
-    hipLaunchKernelGGL((wgrad_reduce_kernel<float, bf16_raw>), grid, dim3(256), 0, stream, partial, S, numel,
-                       (float*)out, accumulate, bias_partial, bias_numel, (bf16_raw*)bias_out, bias_blocks);
+#define PDA_REDUCE(OUT_T, BIAS_T)                                                                             \
+  hipLaunchKernelGGL((wgrad_reduce_kernel<OUT_T, BIAS_T>), grid, dim3(256), 0, stream, partial, S, numel,       \
+                     (OUT_T*)out, accumulate, bias_partial, bias_numel, (BIAS_T*)bias_out, bias_accumulate, \
+                     bias_blocks)
+  if (out_dtype == kBF16) {
+    if (bias_dtype == kBF16) PDA_REDUCE(bf16_raw, bf16_raw); else PDA_REDUCE(bf16_raw, float);
+  } else {
+    if (bias_dtype == kBF16) PDA_REDUCE(float, bf16_raw); else PDA_REDUCE(float, float);
+  }
+#undef PDA_REDUCE
 }
 
 }  // namespace pda

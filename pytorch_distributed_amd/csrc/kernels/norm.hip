@@ -255,7 +255,13 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
 constexpr int kReduceGroups = 16;
 template <typename OutT>
 __global__ __launch_bounds__(64 * kReduceGroups) void reduce_partials_kernel(
-    const float* __restrict__ partial, int partial_rows, int d, OutT* __restrict__ out, bool accumulate) {
+    const float* __restrict__ partial0, OutT* __restrict__ out0, bool accumulate0,
+    const float* __restrict__ partial1, OutT* __restrict__ out1, bool accumulate1, int partial_rows, int d) {
+  // blockIdx.y picks the (partial matrix, output, accumulate) triple: weight and bias gradients
+  // of one LayerNorm are folded by one launch.
+  const float* __restrict__ partial = blockIdx.y == 0 ? partial0 : partial1;
+  OutT* __restrict__ out = blockIdx.y == 0 ? out0 : out1;
+  const bool accumulate = blockIdx.y == 0 ? accumulate0 : accumulate1;
   __shared__ float sm[kReduceGroups][64];
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 64 + lane;
@@ -377,19 +383,24 @@ void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const v
 }
 
 void norm_reduce_partials(const float* dw_partial, const float* db_partial, int partial_rows, int d,
-                          DType out_dtype, void* dweight, void* dbias, bool accumulate,
-                          hipStream_t stream) {
-  dim3 grid((d + 63) / 64), block(64 * kReduceGroups);
-  for (int which = 0; which < 2; ++which) {
-    const float* src = which == 0 ? dw_partial : db_partial;
-    void* dst = which == 0 ? dweight : dbias;
-    if (!src || !dst) continue;
-    if (out_dtype == kBF16)
-      hipLaunchKernelGGL(reduce_partials_kernel<bf16_raw>, grid, block, 0, stream, src, partial_rows,
-                         d, (bf16_raw*)dst, accumulate);
+                          DType dw_dtype, void* dweight, bool accumulate_w, DType db_dtype, void* dbias,
+                          bool accumulate_b, hipStream_t stream) {
+  const dim3 block(64 * kReduceGroups);
+  auto launch = [&](DType dt, const float* p0, void* o0, bool a0, const float* p1, void* o1, bool a1, int n) {
+    const dim3 grid((d + 63) / 64, n);
+    if (dt == kBF16)
+      hipLaunchKernelGGL(reduce_partials_kernel<bf16_raw>, grid, block, 0, stream, p0, (bf16_raw*)o0, a0, p1,
+                         (bf16_raw*)o1, a1, partial_rows, d);
     else
-      hipLaunchKernelGGL(reduce_partials_kernel<float>, grid, block, 0, stream, src, partial_rows, d,
-                         (float*)dst, accumulate);
+      hipLaunchKernelGGL(reduce_partials_kernel<float>, grid, block, 0, stream, p0, (float*)o0, a0, p1, (float*)o1,
+                         a1, partial_rows, d);
+  };
+  const bool has_w = dw_partial && dweight, has_b = db_partial && dbias;
+  if (has_w && has_b && dw_dtype == db_dtype) {
+    launch(dw_dtype, dw_partial, dweight, accumulate_w, db_partial, dbias, accumulate_b, 2);
+  } else {
+    if (has_w) launch(dw_dtype, dw_partial, dweight, accumulate_w, nullptr, nullptr, false, 1);
+    if (has_b) launch(db_dtype, db_partial, dbias, accumulate_b, nullptr, nullptr, false, 1);
   }
 }
 

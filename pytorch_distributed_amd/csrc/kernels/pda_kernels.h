@@ -65,8 +65,8 @@ void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const v
                    const float* mean, const float* rstd, const void* dresidual, void* dx,
                    float* dw_partial, float* db_partial, int64_t rows, int d, hipStream_t stream);
 void norm_reduce_partials(const float* dw_partial, const float* db_partial, int partial_rows, int d,
-                          DType out_dtype, void* dweight, void* dbias, bool accumulate,
-                          hipStream_t stream);
+                          DType dw_dtype, void* dweight, bool accumulate_w, DType db_dtype, void* dbias,
+                          bool accumulate_b, hipStream_t stream);
 
 // -------------------------------------------------------------- Activations --
 // tanh-approximated GELU ("gelu_new"): y = 0.5 u (1 + tanh(sqrt(2/pi)(u + 0.044715 u^3))).
@@ -127,7 +127,8 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream);
 // bias_partial (optional, [S][bias_numel]) is folded into bias_out (bf16) by the same launch.
 void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
-                  const float* bias_partial, int64_t bias_numel, void* bias_out, hipStream_t stream);
+                  const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
+                  bool bias_accumulate, hipStream_t stream);
 
 // ----------------------------------------------------------------- Utilities --
 // dst(fp32) += src(bf16) * scale, and plain casts, for main-grad accumulation.

@@ -111,6 +111,17 @@ def input_grad_mm(dy2: torch.Tensor, weight: torch.Tensor, dy_padded: torch.Tens
     return transposed() if choice else direct()
 
 
+def _grad_target(param, sink):
+    """Where a parameter's gradient kernel should write: ``(tensor, accumulate)`` from the owner's
+    sink, else the existing contiguous ``.grad`` (accumulate), else None (fresh tensor to autograd)."""
+    if param is None:
+        return None
+    target = sink() if sink is not None else None
+    if target is None and param.grad is not None and param.grad.is_contiguous():
+        target = (param.grad, True)
+    return target
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -119,6 +130,8 @@ class _LinearFn(torch.autograd.Function):
         # Gradient sink: a sharding / reducing wrapper that owns a flat gradient buffer tags the
         # weight with a callable returning (slice_of_flat_buffer, accumulate).
         ctx.grad_sink = getattr(weight, "_pda_grad_sink", None)
+        ctx.bias_sink = getattr(bias, "_pda_grad_sink", None)
+        ctx.bias = bias  # only consulted for its .grad / sink; the values are not needed in backward
         x2 = x.reshape(-1, x.shape[-1])
         # The result is allocated in its final shape (not returned as a view of a 2-D tensor), so
         # a following op may legally work on it in place (the rotary kernel does).
@@ -138,20 +151,18 @@ class _LinearFn(torch.autograd.Function):
         if need_w and _native_wgrad_ok(dy2, x2):
             if not dy2.is_contiguous():
                 dy2 = dy2.contiguous()
-            target = ctx.grad_sink() if ctx.grad_sink is not None else None
-            if target is None and weight.grad is not None and weight.grad.is_contiguous():
-                # Gradient accumulation without a wrapper: add into the existing .grad in the
-                # kernel's reduction pass rather than materialise dW for autograd to add.
-                target = (weight.grad, True)
-            if target is not None:
-                # The kernel's slice-reduction pass writes straight into the owner's flat buffer.
-                # Autograd gets no weight gradient (None): the parameter's accumulator node still
-                # runs, so the owner's hook on it fires and counts the parameter as ready.
-                slot, accumulate = target
-                _, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), slot, accumulate)
-            else:
-                dw, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b))
-            if need_b:
+            # The kernel's slice-reduction pass writes (or adds) each gradient straight into its
+            # target: the owner's flat buffer (gradient sink), or an existing .grad when gradients
+            # are accumulated without a wrapper. Autograd then gets None for that parameter; its
+            # accumulator node still runs, so the owner's hook on it fires and counts it as ready.
+            w_target = _grad_target(weight, ctx.grad_sink)
+            b_target = _grad_target(ctx.bias, ctx.bias_sink) if need_b else None
+            w_out, w_acc = w_target if w_target is not None else (None, False)
+            b_out, b_acc = b_target if b_target is not None else (None, False)
+            dw_native, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), w_out, w_acc,
+                                                               b_out, b_acc)
+            dw = dw_native if w_target is None else None
+            if need_b and b_target is None:
                 db = db_native
         else:
             if need_w:

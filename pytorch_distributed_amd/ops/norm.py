@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _ext
+from .linear import _grad_target
 
 
 # --------------------------------------------------------------------------- reference
@@ -48,6 +49,10 @@ class _FusedNormFn(torch.autograd.Function):
             h = x
         ctx.rms = rms
         ctx.has_residual = res is not None
+        # Gradient sinks (see ops.linear): the owner of a flat gradient buffer tags its
+        # parameters with a callable returning (slice_of_buffer, accumulate).
+        ctx.params = (weight, bias)
+        ctx.sinks = (getattr(weight, "_pda_grad_sink", None), getattr(bias, "_pda_grad_sink", None))
         ctx.save_for_backward(h, weight, mean if not rms else None, rstd)
         ctx.set_materialize_grads(False)  # an unused output arrives as None, not as zeros
         return y, h
@@ -60,8 +65,15 @@ class _FusedNormFn(torch.autograd.Function):
             return dh, (dh if ctx.has_residual else None), None, None, None, None
         dy = dy.contiguous()
         dres = dh.contiguous() if dh is not None else None
-        dx, dw, db = ext.norm_backward(dy, h, weight, mean, rstd, dres, ctx.rms)
-        return dx, (dx if ctx.has_residual else None), dw, (None if ctx.rms else db), None, None
+        w_target = _grad_target(ctx.params[0], ctx.sinks[0]) if ctx.needs_input_grad[2] else None
+        b_target = _grad_target(ctx.params[1], ctx.sinks[1]) if not ctx.rms and ctx.needs_input_grad[3] else None
+        w_out, w_acc = w_target if w_target is not None else (None, False)
+        b_out, b_acc = b_target if b_target is not None else (None, False)
+        dx, dw, db = ext.norm_backward(dy, h, weight, mean, rstd, dres, ctx.rms, w_out, w_acc, b_out, b_acc)
+        # A gradient written into its sink is reported to autograd as None (the accumulator
+        # node still runs and fires the owner's hook).
+        return (dx, (dx if ctx.has_residual else None), (dw if w_target is None else None),
+                (db if not ctx.rms and b_target is None else None), None, None)
 
 
 def fused_add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,

@@ -72,10 +72,10 @@ class DDP(nn.Module):
                                        int(first_bucket_mb * 2**20), force_collectives)
         for p in params:
             p._pda_grad_is_view = True  # optimizers must zero these in place, never drop them
-            if p.dim() == 2:
-                # ops.linear adds its weight gradient straight into the bucket view instead of
-                # materialising it for autograd to add (the hook on the accumulator still fires).
-                p._pda_grad_sink = functools.partial(_bucket_slot, p)
+            # ops.linear / ops.norm add their parameter gradients straight into the bucket view
+            # instead of materialising them for autograd to add (the hook on the accumulator
+            # still fires).
+            p._pda_grad_sink = functools.partial(_bucket_slot, p)
 
     # -- module surface ----------------------------------------------------------------
     def forward(self, *args, **kwargs):

@@ -97,8 +97,7 @@ class FSDP(nn.Module):
         # weight-gradient kernel writes there directly instead of producing a tensor that the
         # gradient hook then copies (one copy kernel per parameter and micro-batch).
         for i, p in enumerate(mine):
-            if p.dim() == 2:
-                p._pda_grad_sink = functools.partial(self.unit.grad_slot, i)
+            p._pda_grad_sink = functools.partial(self.unit.grad_slot, i)
         # The flat shard is deliberately NOT registered as a module parameter (plain attribute,
         # bypassing nn.Module.__setattr__): state_dict() keeps the original names, .to() never
         # touches it, and parameters() is overridden below to return it.
