@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_distributed_amd import _ext  # noqa: E402
 
 ext = _ext.require()
+if os.environ.get("CAND"):  # widen the planner's candidate list (default 48)
+    ext.gemm_planner_configure(True, int(os.environ["CAND"]), int(os.environ.get("RUNS", 4)))
 M = int(os.environ.get("M", 32768))
 d = int(os.environ.get("D", 1280))
 V = 50304
