@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=None)
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="attention / residual / embedding dropout probability (GPT-2 configurations; 0 = off)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
     ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",
@@ -89,6 +91,8 @@ def main():
         init_distributed(backend="nccl")
 
     cfg = get_config(args.model).without_dropout()
+    if args.dropout > 0 and hasattr(cfg, "attn_pdrop"):
+        cfg.attn_pdrop = cfg.resid_pdrop = cfg.embd_pdrop = args.dropout
     torch.manual_seed(42)
     if hasattr(cfg, "intermediate_size"):  # Llama-style configuration
         from pytorch_distributed_amd.models import LlamaForCausalLM
@@ -175,6 +179,7 @@ def main():
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2**30,
             "config": {"model": args.model, "global_batch": global_batch, "micro_batch": args.micro_batch,
                        "grad_accum": accum, "seq_len": args.seq_len, "parallelism": parallelism,
+                       "dropout": args.dropout,
                        "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
                        "flops_per_token": fpt, "tuned_gemm_table": tuned, "hip_graph": bool(args.hip_graph)},
         })

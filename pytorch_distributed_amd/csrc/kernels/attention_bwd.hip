@@ -167,18 +167,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         // dP of a dropped probability is zero and of a kept one is scaled: rebuild dP from the
         // chain's (dP - delta) before the softmax gradient. The mask is the forward's.
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+          uint32_t words[4];
+          dropout_words_for_query(drop, bh, q_row, key0 + kb * 32, h, lane, words);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int kbase = key0 + kb * 32 + 8 * g + 4 * h;
-            const u32x4 blk = dropout_block(drop, bh, q_row, kbase);
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const bool keep = dropout_keep(drop, blk, q_row, kbase + e);
+              const bool keep = ((words[g] >> (8 * e)) & 0xffu) >= drop.threshold;
               const float dp_true = dp_acc[kb][4 * g + e] + delta;
               dp_acc[kb][4 * g + e] = (keep ? dp_true * drop.keep_scale : 0.f) - delta;
             }
-          }
+        }
       }
       if (__builtin_expect(diag, 0)) softmax_grad(std::true_type{});
       else softmax_grad(std::false_type{});
@@ -342,15 +342,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         // the undropped P times (keep * dP / (1 - p) - delta). keep_mask bit i = element i kept.
         uint32_t keep_mask = 0xffffu;
         if (kDrop) {
-          keep_mask = 0;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int qbase = qs + 8 * g + 4 * h;  // this lane's queries qbase .. qbase + 3 (one key)
-            const u32x4 blk = dropout_block(drop, bh, qbase, key);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (dropout_keep(drop, blk, qbase + e, key)) keep_mask |= 1u << (4 * g + e);
-          }
+          keep_mask = dropout_keep_mask_for_key(drop, bh, qs, h, key, lane);
         }
         auto softmax_grad = [&](auto masked) {
 #pragma unroll

@@ -157,6 +157,76 @@ __device__ __forceinline__ bool dropout_keep(const DropoutParams& dp, const u32x
   return ((word >> (8 * (key & 3))) & 0xffu) >= dp.threshold;
 }
 
+// ---- sharing Philox calls across a quad -------------------------------------------------
+// In every kernel the four lanes of a quad (lanes 4m .. 4m+3) own four consecutive queries (or
+// keys), i.e. one side of a 4 x 4 dropout block, and walk over groups of four consecutive keys
+// (queries) on the other side. All four lanes therefore need the same blocks. Instead of every
+// lane evaluating every block (7 Philox rounds, ~60 instructions, for one useful word), lane j
+// evaluates the block of group j and the quad exchanges words with DPP moves.
+// These helpers must execute with all 64 lanes active.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+  return uint32_t(__builtin_amdgcn_mov_dpp(int(v), kCtrl, 0xf, 0xf, true));
+}
+
+// 4 x 4 transpose across a quad: on entry lane j holds w[0..3]; on exit lane r holds, in w[g],
+// what lane g held in w[r].
+__device__ __forceinline__ void quad_transpose(uint32_t (&w)[4], int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+  const uint32_t a = quad_perm<0xB1>(odd ? w[0] : w[1]);  // exchange with lane ^ 1
+  const uint32_t b = quad_perm<0xB1>(odd ? w[2] : w[3]);
+  if (odd) {
+    w[0] = a;
+    w[2] = b;
+  } else {
+    w[1] = a;
+    w[3] = b;
+  }
+  const uint32_t c = quad_perm<0x4E>(hi ? w[0] : w[2]);  // exchange with lane ^ 2
+  const uint32_t d = quad_perm<0x4E>(hi ? w[1] : w[3]);
+  if (hi) {
+    w[0] = c;
+    w[1] = d;
+  } else {
+    w[2] = c;
+    w[3] = d;
+  }
+}
+
+// Query-per-lane kernels (forward, dQ): this lane's query is `query` (query & 3 == lane & 3) and
+// its accumulator registers 4g .. 4g+3 hold keys kfirst + 8g + 4h .. +3 for g = 0..3. Returns in
+// words[g] the random word of (query, that key group): byte e decides key kfirst + 8g + 4h + e.
+__device__ __forceinline__ void dropout_words_for_query(const DropoutParams& dp, int bh, int query, int kfirst,
+                                                        int h, int lane, uint32_t (&words)[4]) {
+  const u32x4 blk = dropout_block(dp, bh, query, kfirst + 8 * (lane & 3) + 4 * h);
+  words[0] = blk[0];
+  words[1] = blk[1];
+  words[2] = blk[2];
+  words[3] = blk[3];
+  quad_transpose(words, lane);
+}
+
+// Key-per-lane kernel (dK/dV): this lane's key is `key` (key & 3 == lane & 3) and its accumulator
+// registers 4g .. 4g+3 hold queries qfirst + 8g + 4h .. +3. Returns a 16-bit mask: bit 4g + e is
+// set when element (query qfirst + 8g + 4h + e, key) is kept.
+__device__ __forceinline__ uint32_t dropout_keep_mask_for_key(const DropoutParams& dp, int bh, int qfirst, int h,
+                                                              int key, int lane) {
+  const u32x4 blk = dropout_block(dp, bh, qfirst + 8 * (lane & 3) + 4 * h, key);
+  const uint32_t shift = 8u * (uint32_t(key) & 3u);
+  uint32_t mask = 0;
+  auto take = [&](uint32_t word, int bit) {
+    if (((word >> shift) & 0xffu) >= dp.threshold) mask |= 1u << bit;
+  };
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    take(quad_perm<0x00>(blk[e]), e);       // group 0: lane 0's block
+    take(quad_perm<0x55>(blk[e]), 4 + e);   // group 1: lane 1's block
+    take(quad_perm<0xAA>(blk[e]), 8 + e);   // group 2
+    take(quad_perm<0xFF>(blk[e]), 12 + e);  // group 3
+  }
+  return mask;
+}
+
 // Cooperative copy of a [kRows][D] bf16 tile from global memory (row stride
 // `row_stride` elements, rows clamped to `last_row`) into registers and from
 // registers into an LDS tile. Split in two so the global latency hides under

@@ -42,7 +42,7 @@ constexpr int kBN = 64;   // keys per tile
 // them in AGPRs and copies every score across for the softmax) and lets three workgroups
 // share a CU.
 template <int D, bool kDrop>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? (kDrop ? 2 : 3) : 2))) void attn_fwd_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2))) void attn_fwd_kernel(
     const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, float* __restrict__ lse_out, int B, int T, int H,
     float scale, DropoutParams drop) {
   constexpr int kKSteps = D / 16;   // k-steps of the S^T product
@@ -170,17 +170,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       // ---- attention dropout: the row sum above is of the undropped probabilities ----------
       if (kDrop) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+          uint32_t words[4];  // words[g]: keys key0 + 32 kb + 8 g + 4 h .. +3 of this lane's query
+          dropout_words_for_query(drop, bh, q_row, key0 + kb * 32, h, lane, words);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int kbase = key0 + kb * 32 + 8 * g + 4 * h;  // this lane's keys kbase .. kbase + 3
-            const u32x4 blk = dropout_block(drop, bh, q_row, kbase);
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const bool keep = dropout_keep(drop, blk, q_row, kbase + e);
+              const bool keep = ((words[g] >> (8 * e)) & 0xffu) >= drop.threshold;
               s_acc[kb][4 * g + e] = keep ? s_acc[kb][4 * g + e] * drop.keep_scale : 0.f;
             }
-          }
+        }
       }
       // ---- O^T += V^T . P^T ---------------------------------------------------
 #pragma unroll

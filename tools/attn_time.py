@@ -1,4 +1,5 @@
-"""Times the attention kernels with HIP events (GPT-2 Large shape by default)."""
+"""Times the attention kernels with HIP events (GPT-2 Large shape by default), without and with
+attention dropout."""
 import os
 import sys
 
@@ -27,8 +28,9 @@ def bench(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-out, lse = ext.attention_forward(qkv, H, sc)
-tf = bench(lambda: ext.attention_forward(qkv, H, sc))
-tb = bench(lambda: ext.attention_backward(qkv, out, dout, lse, H, sc))
 fl = 4 * B * H * T * T * D / 2
-print(f"B={B} T={T} H={H} D={D}: fwd {tf:.1f} us ({fl / tf / 1e6:.0f} TF causal)  bwd {tb:.1f} us ({2.5 * fl / tb / 1e6:.0f} TF causal, 5-GEMM count)")
+for p in (0.0, float(os.environ.get("DROPOUT", 0.1))):
+    out, lse = ext.attention_forward(qkv, H, sc, p, 1234)
+    tf = bench(lambda: ext.attention_forward(qkv, H, sc, p, 1234))
+    tb = bench(lambda: ext.attention_backward(qkv, out, dout, lse, H, sc, p, 1234))
+    print(f"B={B} T={T} H={H} D={D} dropout={p}: fwd {tf:.1f} us ({fl / tf / 1e6:.0f} TF causal)  bwd {tb:.1f} us ({2.5 * fl / tb / 1e6:.0f} TF causal, 5-GEMM count)")
