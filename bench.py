@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--bucket-mb", type=float, default=None)
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--init-device", choices=["auto", "cpu", "gpu"], default="auto",
+                    help="construct the model on the host (then move) or directly on the GPU; auto = GPU above 1e9 parameters")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="attention / residual / embedding dropout probability (GPT-2 configurations; 0 = off)")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
@@ -94,12 +96,17 @@ def main():
     if args.dropout > 0 and hasattr(cfg, "attn_pdrop"):
         cfg.attn_pdrop = cfg.resid_pdrop = cfg.embd_pdrop = args.dropout
     torch.manual_seed(42)
-    if hasattr(cfg, "intermediate_size"):  # Llama-style configuration
-        from pytorch_distributed_amd.models import LlamaForCausalLM
-        model = LlamaForCausalLM(cfg)
-    else:
-        model = MyGPT2LMHeadModel(cfg)
+    import contextlib
+    from pytorch_distributed_amd.models import LlamaForCausalLM, init_on_device
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cls = LlamaForCausalLM if hasattr(cfg, "intermediate_size") else MyGPT2LMHeadModel
+    on_gpu = args.init_device == "gpu"
+    if args.init_device == "auto":
+        with init_on_device("meta"):
+            on_gpu = sum(p.numel() for p in cls(cfg).parameters()) > 1e9
+    torch.cuda.manual_seed(42)
+    with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
+        model = cls(cfg)
     model = model.to(device=device, dtype=dtype)
 
     parallelism = "single"

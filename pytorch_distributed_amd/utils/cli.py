@@ -10,6 +10,7 @@ reference's run; everything else is opt-in.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import glob
 import os
 from typing import List, Optional
@@ -33,6 +34,10 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default=None, help="default: bf16 on GPU, fp32 on CPU")
     ap.add_argument("--dropout", type=float, default=None, help="override all dropout probabilities (config: 0.1)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--init-device", choices=["cpu", "gpu"], default="cpu",
+                    help="where the model is constructed: cpu = fp32 on the host then moved (the reference's order, "
+                         "same weights as a CPU run); gpu = directly on the training device in the training dtype "
+                         "(multi-billion-parameter models)")
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--synthetic-data", action="store_true", help="random tokens generated on the device")
     ap.add_argument("--data-dir", default=".cache/data/fineweb10B")
@@ -65,11 +70,14 @@ def build_model(args, device, dtype):
     torch.manual_seed(args.seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed(args.seed)
-    if hasattr(cfg, "intermediate_size"):
-        from ..models.llama import LlamaForCausalLM
-        model = LlamaForCausalLM(cfg)
-    else:
-        model = MyGPT2LMHeadModel(cfg, activation_checkpoint=args.activation_checkpoint)
+    from ..models import init_on_device
+    on_gpu = getattr(args, "init_device", "cpu") == "gpu" and torch.device(device).type == "cuda"
+    with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
+        if hasattr(cfg, "intermediate_size"):
+            from ..models.llama import LlamaForCausalLM
+            model = LlamaForCausalLM(cfg)
+        else:
+            model = MyGPT2LMHeadModel(cfg, activation_checkpoint=args.activation_checkpoint)
     return model.to(device=device, dtype=dtype), cfg
 
 

@@ -369,3 +369,19 @@ def test_capturable_adamw_on_cpu_is_plain_adamw_and_graph_step_needs_it():
     assert int(o2.state_dict()["state"][0]["step"]) == 5
     with pytest.raises(ValueError, match="capturable"):
         GraphedTrainStep(torch.nn.Linear(2, 2), o1, 1, 4, device=torch.device("cpu"))
+
+
+def test_init_on_device_meta_and_dtype():
+    """Models can be built without host storage (meta) or directly in the training dtype."""
+    from pytorch_distributed_amd.models import LlamaForCausalLM, get_config, init_on_device
+
+    with init_on_device("meta"):
+        big = LlamaForCausalLM(get_config("llama-7b"))
+    assert all(p.is_meta for p in big.parameters())
+    assert abs(sum(p.numel() for p in big.parameters()) - 6.738e9) < 1e7
+    with init_on_device("cpu", torch.bfloat16):
+        m = LlamaForCausalLM(get_config("llama-tiny"))
+    assert all(p.dtype == torch.bfloat16 for p in m.parameters())
+    assert torch.get_default_dtype() == torch.float32
+    ids = torch.randint(0, 512, (2, 17))
+    assert torch.isfinite(m(ids[:, :-1], ids[:, 1:]).float())
