@@ -43,8 +43,10 @@ void check_launch(const char* what) {
 // ------------------------------------------------------------------ norms --
 std::vector<at::Tensor> norm_forward(const at::Tensor& x, const std::optional<at::Tensor>& residual,
                                      const at::Tensor& weight, const std::optional<at::Tensor>& bias,
-                                     double eps, bool rms) {
+                                     double eps, bool rms, double dropout_p, uint64_t seed) {
   check_gpu(x, "x");
+  TORCH_CHECK(dropout_p >= 0.0 && dropout_p < 1.0, "norm: dropout probability must be in [0, 1)");
+  TORCH_CHECK(dropout_p == 0.0 || !rms, "norm: fused dropout is implemented for LayerNorm only");
   check_gpu(weight, "weight");
   const c10::DeviceGuard guard(x.device());
   const int64_t d = x.size(-1);
@@ -68,6 +70,8 @@ std::vector<at::Tensor> norm_forward(const at::Tensor& x, const std::optional<at
                 "norm: residual must match x");
     res_ptr = residual->data_ptr();
     sum_out = at::empty_like(x);
+  } else if (dropout_p > 0.0) {
+    sum_out = at::empty_like(x);  // the normalised row is dropout(x), not x: it is emitted too
   }
   at::Tensor y = at::empty_like(x);
   auto stat_opts = x.options().dtype(at::kFloat);
@@ -76,7 +80,7 @@ std::vector<at::Tensor> norm_forward(const at::Tensor& x, const std::optional<at
   pda::norm_forward(dt, rms, x.data_ptr(), res_ptr, weight.data_ptr(), bias_ptr, y.data_ptr(),
                     sum_out.defined() ? sum_out.data_ptr() : nullptr,
                     rms ? nullptr : mean.data_ptr<float>(), rstd.data_ptr<float>(), rows, (int)d,
-                    (float)eps, current_stream());
+                    (float)eps, (float)dropout_p, seed, current_stream());
   check_launch("norm_forward");
   return {y, sum_out, mean, rstd};
 }
@@ -85,7 +89,10 @@ std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
                                       const at::Tensor& weight, const std::optional<at::Tensor>& mean,
                                       const at::Tensor& rstd, const std::optional<at::Tensor>& dresidual,
                                       bool rms, const std::optional<at::Tensor>& dweight_out, bool accumulate_w,
-                                      const std::optional<at::Tensor>& dbias_out, bool accumulate_b) {
+                                      const std::optional<at::Tensor>& dbias_out, bool accumulate_b,
+                                      double dropout_p, uint64_t seed) {
+  TORCH_CHECK(dropout_p >= 0.0 && dropout_p < 1.0, "norm: dropout probability must be in [0, 1)");
+  TORCH_CHECK(dropout_p == 0.0 || !rms, "norm: fused dropout is implemented for LayerNorm only");
   check_gpu(dy, "dy");
   check_gpu(x, "x");
   check_gpu(weight, "weight");
@@ -114,14 +121,17 @@ std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
     dres_ptr = dresidual->data_ptr();
   }
   at::Tensor dx = at::empty_like(x);
+  // With dropout the branch input gets the masked gradient, the residual stream the full one.
+  at::Tensor dx_branch = dropout_p > 0.0 ? at::empty_like(x) : at::Tensor();
   const int prow = pda::norm_backward_partial_rows(rows);
   auto f32 = x.options().dtype(at::kFloat);
   at::Tensor dwp = at::empty({prow, d}, f32);
   at::Tensor dbp = rms ? at::Tensor() : at::empty({prow, d}, f32);
   hipStream_t stream = current_stream();
   pda::norm_backward(dt, rms, dy.data_ptr(), x.data_ptr(), weight.data_ptr(), mean_ptr,
-                     rstd.data_ptr<float>(), dres_ptr, dx.data_ptr(), dwp.data_ptr<float>(),
-                     rms ? nullptr : dbp.data_ptr<float>(), rows, (int)d, stream);
+                     rstd.data_ptr<float>(), dres_ptr, dx.data_ptr(),
+                     dx_branch.defined() ? dx_branch.data_ptr() : nullptr, dwp.data_ptr<float>(),
+                     rms ? nullptr : dbp.data_ptr<float>(), rows, (int)d, (float)dropout_p, seed, stream);
   check_launch("norm_backward");
   // Parameter gradients go into fresh tensors, or (written / accumulated) into the tensors the
   // caller supplies: slices of a reducer's flat gradient buffer, or existing .grad tensors.
@@ -141,7 +151,7 @@ std::vector<at::Tensor> norm_backward(const at::Tensor& dy, const at::Tensor& x,
                             dtype_of(dw), dw.data_ptr(), accumulate_w, rms ? pda::kF32 : dtype_of(db),
                             rms ? nullptr : db.data_ptr(), accumulate_b, stream);
   check_launch("norm_reduce_partials");
-  return {dx, dw, db};
+  return {dx, dw, db, dx_branch};
 }
 
 // ------------------------------------------------------------ activations --
@@ -467,10 +477,11 @@ void bind_ops(py::module_& m) {
         py::arg("out") = py::none(), py::arg("accumulate") = false, py::arg("bias_out") = py::none(),
         py::arg("bias_accumulate") = false);
   m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
-        py::arg("bias"), py::arg("eps"), py::arg("rms"));
+        py::arg("bias"), py::arg("eps"), py::arg("rms"), py::arg("dropout_p") = 0.0, py::arg("seed") = 0);
   m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"),
         py::arg("rstd"), py::arg("dresidual"), py::arg("rms"), py::arg("dweight_out") = py::none(),
-        py::arg("accumulate_w") = false, py::arg("dbias_out") = py::none(), py::arg("accumulate_b") = false);
+        py::arg("accumulate_w") = false, py::arg("dbias_out") = py::none(), py::arg("accumulate_b") = false,
+        py::arg("dropout_p") = 0.0, py::arg("seed") = 0);
   m.def("gelu_forward", &gelu_forward);
   m.def("gelu_backward", &gelu_backward);
   m.def("swiglu_forward", &swiglu_forward);

@@ -25,6 +25,7 @@
 #pragma once
 
 #include "common.h"
+#include "philox.h"
 
 namespace pda {
 namespace attn {
@@ -111,40 +112,6 @@ __device__ __forceinline__ float lane_pair_sum(float v) { return v + __shfl_xor(
 // A lane owns four consecutive keys of one query in the forward / dQ kernels and four
 // consecutive queries of one key in the dK/dV kernel, so either orientation needs exactly
 // one call per four elements. Seven rounds (the "Crush-resistant" count of the Philox paper).
-struct DropoutParams {
-  uint32_t seed_lo, seed_hi;
-  uint32_t threshold;  // 0 disables dropout
-  float keep_scale;    // 256 / (256 - threshold)
-};
-
-inline DropoutParams make_dropout_params(float p, uint64_t seed) {
-  DropoutParams d;
-  d.seed_lo = uint32_t(seed);
-  d.seed_hi = uint32_t(seed >> 32);
-  int thr = int(p * 256.f + 0.5f);
-  thr = thr < 0 ? 0 : (thr > 255 ? 255 : thr);
-  d.threshold = uint32_t(thr);
-  d.keep_scale = 256.f / float(256 - thr);
-  return d;
-}
-
-__device__ __forceinline__ u32x4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1) {
-  constexpr uint32_t kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
-#pragma unroll
-  for (int round = 0; round < 7; ++round) {
-    const uint32_t hi0 = __umulhi(kM0, c0), lo0 = kM0 * c0;
-    const uint32_t hi1 = __umulhi(kM1, c2), lo1 = kM1 * c2;
-    c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
-    c3 = lo0;
-    k0 += kW0;
-    k1 += kW1;
-  }
-  return u32x4{c0, c1, c2, c3};
-}
-
 // The four random words of the 4 x 4 block holding (query, key).
 __device__ __forceinline__ u32x4 dropout_block(const DropoutParams& dp, int bh, int query, int key) {
   return philox4x32_7(uint32_t(query) >> 2, uint32_t(key) >> 2, uint32_t(bh), 0u, dp.seed_lo, dp.seed_hi);

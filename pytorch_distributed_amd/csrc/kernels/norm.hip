@@ -16,6 +16,7 @@
 // partial row; norm_reduce_partials folds the <= 512 partial rows.
 #include "common.h"
 #include "pda_kernels.h"
+#include "philox.h"
 
 namespace pda {
 namespace {
@@ -24,11 +25,28 @@ constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / kWave;
 constexpr int kMaxPartialRows = 512;
 
-template <typename T, int kMaxIt, bool kRms, bool kHasRes>
+using attn::DropoutParams;
+
+// Dropout on the branch input x of the fused "x + residual" (the residual / embedding dropout
+// of the reference, assignments/assignment1/model/my_gpt2.py:55-56,97-98,172): element k of
+// 16-byte vector `vi` of row `row` is kept when byte k of Philox(row, vi; seed) >= threshold.
+// Forward and backward call this with the same coordinates, so no mask is stored.
+template <int kVec>
+__device__ __forceinline__ uint32_t dropout_keep_bits(const DropoutParams& dp, int64_t row, int vi) {
+  const u32x4 r = attn::philox4x32_7(uint32_t(row), uint32_t(uint64_t(row) >> 32), uint32_t(vi), 0x6e6f726du,
+                                     dp.seed_lo, dp.seed_hi);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int k = 0; k < kVec; ++k)
+    if (((r[k >> 2] >> (8 * (k & 3))) & 0xffu) >= dp.threshold) bits |= 1u << k;
+  return bits;
+}
+
+template <typename T, int kMaxIt, bool kRms, bool kHasRes, bool kDrop>
 __global__ __launch_bounds__(kThreads) void norm_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ w,
     const T* __restrict__ b, T* __restrict__ y, T* __restrict__ sum_out, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out, int64_t rows, int d, float eps) {
+    float* __restrict__ rstd_out, int64_t rows, int d, float eps, DropoutParams drop) {
   constexpr int kVec = VecIO<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int nvec = d / kVec;
@@ -45,11 +63,18 @@ __global__ __launch_bounds__(kThreads) void norm_fwd_kernel(
       const int vi = lane + it * 64;
       if (vi < nvec) {
         VecIO<T>::load(xr + vi * kVec, v[it]);
+        if (kDrop) {
+          const uint32_t keep = dropout_keep_bits<kVec>(drop, row, vi);
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) v[it][k] = (keep >> k) & 1u ? v[it][k] * drop.keep_scale : 0.f;
+        }
         if (kHasRes) {
           float r[kVec];
           VecIO<T>::load(res + row * d + vi * kVec, r);
 #pragma unroll
           for (int k = 0; k < kVec; ++k) v[it][k] += r[k];
+        }
+        if (kHasRes || kDrop) {  // the normalised row differs from x: emit it as the new residual stream
           VecIO<T>::store(sum_out + row * d + vi * kVec, v[it]);
           if constexpr (sizeof(T) == 2) {
             // Normalise what later kernels will read back: the bf16-rounded sum.
@@ -104,12 +129,14 @@ __global__ __launch_bounds__(kThreads) void norm_fwd_kernel(
   }
 }
 
-template <typename T, int kMaxIt, bool kRms, bool kHasRes>
+// With kDrop the gradient of the normalised row goes to `dx` (the residual stream's share) and
+// its masked, rescaled copy to `dx_branch` (the share of the branch that was dropped out).
+template <typename T, int kMaxIt, bool kRms, bool kHasRes, bool kDrop>
 __global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ dw_partial,
-    float* __restrict__ db_partial, int64_t rows, int d) {
+    const T* __restrict__ dres, T* __restrict__ dx, T* __restrict__ dx_branch, float* __restrict__ dw_partial,
+    float* __restrict__ db_partial, int64_t rows, int d, DropoutParams drop) {
   constexpr int kVec = VecIO<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -200,6 +227,12 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_kernel(
           for (int k = 0; k < kVec; ++k) o[k] += r[k];
         }
         VecIO<T>::store(dx + row * d + vi * kVec, o);
+        if (kDrop) {
+          const uint32_t keep = dropout_keep_bits<kVec>(drop, row, vi);
+#pragma unroll
+          for (int k = 0; k < kVec; ++k) o[k] = (keep >> k) & 1u ? o[k] * drop.keep_scale : 0.f;
+          VecIO<T>::store(dx_branch + row * d + vi * kVec, o);
+        }
       }
     }
     if (has_next) {
@@ -297,39 +330,43 @@ inline unsigned fwd_grid(int64_t rows) {
 template <typename T, int kMaxIt>
 void launch_fwd(bool rms, const void* x, const void* res, const void* w, const void* b, void* y,
                 void* sum_out, float* mean, float* rstd, int64_t rows, int d, float eps,
-                hipStream_t stream) {
+                const DropoutParams& drop, hipStream_t stream) {
   dim3 grid(fwd_grid(rows)), block(kThreads);
-#define PDA_FWD(RMS, RES)                                                                        \
-  hipLaunchKernelGGL((norm_fwd_kernel<T, kMaxIt, RMS, RES>), grid, block, 0, stream, (const T*)x, \
-                     (const T*)res, (const T*)w, (const T*)b, (T*)y, (T*)sum_out, mean, rstd,     \
-                     rows, d, eps)
-  if (rms) {
-    if (res) PDA_FWD(true, true); else PDA_FWD(true, false);
+#define PDA_FWD(RMS, RES, DROP)                                                                          \
+  hipLaunchKernelGGL((norm_fwd_kernel<T, kMaxIt, RMS, RES, DROP>), grid, block, 0, stream, (const T*)x, \
+                     (const T*)res, (const T*)w, (const T*)b, (T*)y, (T*)sum_out, mean, rstd,           \
+                     rows, d, eps, drop)
+  if (rms) {  // RMSNorm models (Llama-style) have no dropout
+    if (res) PDA_FWD(true, true, false); else PDA_FWD(true, false, false);
+  } else if (drop.threshold) {
+    if (res) PDA_FWD(false, true, true); else PDA_FWD(false, false, true);
   } else {
-    if (res) PDA_FWD(false, true); else PDA_FWD(false, false);
+    if (res) PDA_FWD(false, true, false); else PDA_FWD(false, false, false);
   }
 #undef PDA_FWD
 }
 
 template <typename T, int kMaxIt>
 void launch_bwd(bool rms, const void* dy, const void* x, const void* w, const float* mean,
-                const float* rstd, const void* dres, void* dx, float* dwp, float* dbp, int64_t rows,
-                int d, hipStream_t stream) {
+                const float* rstd, const void* dres, void* dx, void* dx_branch, float* dwp, float* dbp,
+                int64_t rows, int d, const DropoutParams& drop, hipStream_t stream) {
   dim3 grid(norm_backward_partial_rows(rows)), block(kThreads);
   const size_t lds = size_t(3) * d * sizeof(float);
-#define PDA_BWD(RMS, RES)                                                                          \
+#define PDA_BWD(RMS, RES, DROP)                                                                    \
   do {                                                                                             \
     if (lds > 65536)                                                                               \
-      (void)hipFuncSetAttribute((const void*)norm_bwd_kernel<T, kMaxIt, RMS, RES>,                 \
+      (void)hipFuncSetAttribute((const void*)norm_bwd_kernel<T, kMaxIt, RMS, RES, DROP>,           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-    hipLaunchKernelGGL((norm_bwd_kernel<T, kMaxIt, RMS, RES>), grid, block, lds, stream,           \
+    hipLaunchKernelGGL((norm_bwd_kernel<T, kMaxIt, RMS, RES, DROP>), grid, block, lds, stream,     \
                        (const T*)dy, (const T*)x, (const T*)w, mean, rstd, (const T*)dres, (T*)dx, \
-                       dwp, dbp, rows, d);                                                         \
+                       (T*)dx_branch, dwp, dbp, rows, d, drop);                                    \
   } while (0)
   if (rms) {
-    if (dres) PDA_BWD(true, true); else PDA_BWD(true, false);
+    if (dres) PDA_BWD(true, true, false); else PDA_BWD(true, false, false);
+  } else if (drop.threshold) {
+    if (dres) PDA_BWD(false, true, true); else PDA_BWD(false, false, true);
   } else {
-    if (dres) PDA_BWD(false, true); else PDA_BWD(false, false);
+    if (dres) PDA_BWD(false, true, false); else PDA_BWD(false, false, false);
   }
 #undef PDA_BWD
 }
@@ -350,33 +387,36 @@ int norm_backward_partial_rows(int64_t rows) {
 
 void norm_forward(DType dtype, bool rms, const void* x, const void* residual, const void* weight,
                   const void* bias, void* y, void* sum_out, float* mean, float* rstd, int64_t rows,
-                  int d, float eps, hipStream_t stream) {
+                  int d, float eps, float dropout_p, uint64_t seed, hipStream_t stream) {
   if (rows <= 0) return;
+  const DropoutParams drop = attn::make_dropout_params(rms ? 0.f : dropout_p, seed);
 #define PDA_DISPATCH(T)                                                                              \
   do {                                                                                               \
     const int it = iters_for<T>(d);                                                                  \
-    if (it <= 2) launch_fwd<T, 2>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
-    else if (it <= 3) launch_fwd<T, 3>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
-    else if (it <= 4) launch_fwd<T, 4>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
-    else if (it <= 8) launch_fwd<T, 8>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
-    else launch_fwd<T, 16>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, stream); \
+    if (it <= 2) launch_fwd<T, 2>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, drop, stream); \
+    else if (it <= 3) launch_fwd<T, 3>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, drop, stream); \
+    else if (it <= 4) launch_fwd<T, 4>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, drop, stream); \
+    else if (it <= 8) launch_fwd<T, 8>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, drop, stream); \
+    else launch_fwd<T, 16>(rms, x, residual, weight, bias, y, sum_out, mean, rstd, rows, d, eps, drop, stream); \
   } while (0)
   if (dtype == kBF16) PDA_DISPATCH(bf16_raw); else PDA_DISPATCH(float);
 #undef PDA_DISPATCH
 }
 
 void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const void* weight,
-                   const float* mean, const float* rstd, const void* dresidual, void* dx,
-                   float* dw_partial, float* db_partial, int64_t rows, int d, hipStream_t stream) {
+                   const float* mean, const float* rstd, const void* dresidual, void* dx, void* dx_branch,
+                   float* dw_partial, float* db_partial, int64_t rows, int d, float dropout_p, uint64_t seed,
+                   hipStream_t stream) {
   if (rows <= 0) return;
+  const DropoutParams drop = attn::make_dropout_params(rms ? 0.f : dropout_p, seed);
 #define PDA_DISPATCH(T)                                                                              \
   do {                                                                                               \
     const int it = iters_for<T>(d);                                                                  \
-    if (it <= 2) launch_bwd<T, 2>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
-    else if (it <= 3) launch_bwd<T, 3>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
-    else if (it <= 4) launch_bwd<T, 4>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
-    else if (it <= 8) launch_bwd<T, 8>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
-    else launch_bwd<T, 16>(rms, dy, x, weight, mean, rstd, dresidual, dx, dw_partial, db_partial, rows, d, stream); \
+    if (it <= 2) launch_bwd<T, 2>(rms, dy, x, weight, mean, rstd, dresidual, dx, dx_branch, dw_partial, db_partial, rows, d, drop, stream); \
+    else if (it <= 3) launch_bwd<T, 3>(rms, dy, x, weight, mean, rstd, dresidual, dx, dx_branch, dw_partial, db_partial, rows, d, drop, stream); \
+    else if (it <= 4) launch_bwd<T, 4>(rms, dy, x, weight, mean, rstd, dresidual, dx, dx_branch, dw_partial, db_partial, rows, d, drop, stream); \
+    else if (it <= 8) launch_bwd<T, 8>(rms, dy, x, weight, mean, rstd, dresidual, dx, dx_branch, dw_partial, db_partial, rows, d, drop, stream); \
+    else launch_bwd<T, 16>(rms, dy, x, weight, mean, rstd, dresidual, dx, dx_branch, dw_partial, db_partial, rows, d, drop, stream); \
   } while (0)
   if (dtype == kBF16) PDA_DISPATCH(bf16_raw); else PDA_DISPATCH(float);
 #undef PDA_DISPATCH

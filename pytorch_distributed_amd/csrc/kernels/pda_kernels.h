@@ -54,7 +54,7 @@ void adamw_step(const AdamWTensor* tensors, int n, DType grad_dtype, const AdamW
 // and rms = true. Requires d % (16 / sizeof(T)) == 0 and 16-byte aligned rows.
 void norm_forward(DType dtype, bool rms, const void* x, const void* residual, const void* weight,
                   const void* bias, void* y, void* sum_out, float* mean, float* rstd,
-                  int64_t rows, int d, float eps, hipStream_t stream);
+                  int64_t rows, int d, float eps, float dropout_p, uint64_t seed, hipStream_t stream);
 
 // dx = dLN/dx (+ dresidual if given). Column reductions for dweight / dbias
 // are produced as fp32 partial sums [norm_backward_partial_rows(rows), d] and
@@ -62,8 +62,9 @@ void norm_forward(DType dtype, bool rms, const void* x, const void* residual, co
 // adds to the existing contents instead of overwriting).
 int norm_backward_partial_rows(int64_t rows);
 void norm_backward(DType dtype, bool rms, const void* dy, const void* x, const void* weight,
-                   const float* mean, const float* rstd, const void* dresidual, void* dx,
-                   float* dw_partial, float* db_partial, int64_t rows, int d, hipStream_t stream);
+                   const float* mean, const float* rstd, const void* dresidual, void* dx, void* dx_branch,
+                   float* dw_partial, float* db_partial, int64_t rows, int d, float dropout_p, uint64_t seed,
+                   hipStream_t stream);
 void norm_reduce_partials(const float* dw_partial, const float* db_partial, int partial_rows, int d,
                           DType dw_dtype, void* dweight, bool accumulate_w, DType db_dtype, void* dbias,
                           bool accumulate_b, hipStream_t stream);

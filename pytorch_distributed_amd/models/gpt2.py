@@ -50,11 +50,14 @@ class MyGPT2Attention(nn.Module):
         self.attn_pdrop = float(config.attn_pdrop)
         self.resid_dropout = nn.Dropout(p=config.resid_pdrop)
 
-    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True) -> torch.Tensor:
+        """``apply_dropout=False``: the caller applies ``resid_dropout`` itself (the block fuses it
+        into the next LayerNorm kernel)."""
         # [B, T, 3d], consumed in place by the attention kernel
         qkv = ops.linear(hidden_states, self.c_attn.weight, self.c_attn.bias)
         ctx = ops.causal_attention(qkv, self.num_heads, dropout_p=self.attn_pdrop, training=self.training)
-        return self.resid_dropout(ops.linear(ctx, self.c_proj.weight, self.c_proj.bias))
+        out = ops.linear(ctx, self.c_proj.weight, self.c_proj.bias)
+        return self.resid_dropout(out) if apply_dropout else out
 
 
 class MyGPT2MLP(nn.Module):
@@ -70,19 +73,21 @@ class MyGPT2MLP(nn.Module):
         self.c_proj = nn.Linear(4 * self.embed_dim, self.embed_dim, bias=True)
         self.dropout = nn.Dropout(p=config.resid_pdrop)
 
-    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True) -> torch.Tensor:
         u = ops.linear(hidden_states, self.c_fc.weight, self.c_fc.bias)
-        return self.dropout(ops.linear(ops.gelu_new(u), self.c_proj.weight, self.c_proj.bias))
+        out = ops.linear(ops.gelu_new(u), self.c_proj.weight, self.c_proj.bias)
+        return self.dropout(out) if apply_dropout else out
 
 
 class MyGPT2Block(nn.Module):
     """Pre-LayerNorm transformer block.
 
     ``block(x)`` maps a hidden state to a hidden state like the reference's block.
-    ``block(delta, residual)`` is the fused form used by :class:`MyGPT2Model`: the
-    block's input is ``delta + residual`` (added inside the first LayerNorm kernel) and
-    the result is returned as the pair ``(mlp_out, residual')`` whose sum is the block's
-    output, left un-added for the next block's LayerNorm to fuse.
+    ``block(delta, residual, fused=True, delta_pdrop=p)`` is the form used by
+    :class:`MyGPT2Model`: the block's input is ``dropout_p(delta) + residual`` (dropped and
+    added inside the first LayerNorm kernel) and the result is returned as the pair
+    ``(mlp_out, residual')`` with ``mlp_out`` NOT yet dropped out: ``dropout(mlp_out) +
+    residual'`` is the block's output, left for the next LayerNorm kernel to fuse.
     """
 
     def __init__(self, config):
@@ -94,18 +99,25 @@ class MyGPT2Block(nn.Module):
         self.ln_2 = nn.LayerNorm(self.embed_dim, eps=config.layer_norm_epsilon)
         self.mlp = MyGPT2MLP(config)
 
-    def _run(self, delta, residual) -> Tuple[torch.Tensor, torch.Tensor]:
-        y, h = ops.fused_add_layer_norm(delta, residual, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
-        a = self.attn(y)
-        y, h = ops.fused_add_layer_norm(a, h, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
-        return self.mlp(y), h
+    def _run(self, delta, residual, delta_pdrop: float) -> Tuple[torch.Tensor, torch.Tensor]:
+        y, h = ops.fused_add_layer_norm(delta, residual, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps,
+                                        dropout_p=delta_pdrop, training=self.training)
+        a = self.attn(y, apply_dropout=False)
+        y, h = ops.fused_add_layer_norm(a, h, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps,
+                                        dropout_p=self.attn.resid_dropout.p, training=self.training)
+        return self.mlp(y, apply_dropout=False), h
+
+    @property
+    def out_pdrop(self) -> float:
+        """Dropout probability still to be applied to the first element of the fused result."""
+        return self.mlp.dropout.p
 
     def forward(self, hidden_state: torch.Tensor, residual: Optional[torch.Tensor] = None, *,
-                fused: bool = False):
-        out, h = self._run(hidden_state, residual)
+                fused: bool = False, delta_pdrop: float = 0.0):
+        out, h = self._run(hidden_state, residual, delta_pdrop)
         if fused:
             return out, h
-        return out + h
+        return self.mlp.dropout(out) + h
 
 
 class MyGPT2Model(nn.Module):
@@ -131,16 +143,22 @@ class MyGPT2Model(nn.Module):
         if seq_len > self.n_ctx:
             raise ValueError(f"sequence length {seq_len} exceeds n_ctx {self.n_ctx}")
         positions = torch.arange(seq_len, device=input_ids.device)
-        delta = self.drop(self.wte(input_ids) + self.wpe(positions))
+        # Embedding dropout, like every residual dropout below, is applied inside the LayerNorm
+        # kernel that consumes the tensor (`delta_pdrop`).
+        delta = self.wte(input_ids) + self.wpe(positions)
+        pdrop = self.drop.p
         residual = None
         full_recompute = (self.enable_activation_checkpoint and self.training
                           and self.activation_checkpoint == "full")
         for block in self.h:
             if full_recompute:
-                delta, residual = checkpoint(block, delta, residual, fused=True, use_reentrant=False)
+                delta, residual = checkpoint(block, delta, residual, fused=True, delta_pdrop=pdrop,
+                                             use_reentrant=False)
             else:
-                delta, residual = block(delta, residual, fused=True)
-        out, _ = ops.fused_add_layer_norm(delta, residual, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)
+                delta, residual = block(delta, residual, fused=True, delta_pdrop=pdrop)
+            pdrop = block.out_pdrop
+        out, _ = ops.fused_add_layer_norm(delta, residual, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps,
+                                          dropout_p=pdrop, training=self.training)
         return out
 
 

@@ -328,14 +328,22 @@ class _BlockGroup(nn.Module):
         super().__init__()
         self.blocks = nn.ModuleList(blocks)
 
-    def forward(self, hidden, residual=None, *, fused: bool = False):
+    def forward(self, hidden, residual=None, *, fused: bool = False, delta_pdrop: float = 0.0):
         if not fused:
             for b in self.blocks:
                 hidden = b(hidden)
             return hidden
         for b in self.blocks:
-            hidden, residual = b(hidden, residual, fused=True)
+            if hasattr(b, "out_pdrop"):  # blocks whose pending output dropout the next LayerNorm applies
+                hidden, residual = b(hidden, residual, fused=True, delta_pdrop=delta_pdrop)
+                delta_pdrop = b.out_pdrop
+            else:
+                hidden, residual = b(hidden, residual, fused=True)
         return hidden, residual
+
+    @property
+    def out_pdrop(self) -> float:
+        return getattr(self.blocks[-1], "out_pdrop", 0.0)
 
 
 class _GroupedBlockList(nn.ModuleList):

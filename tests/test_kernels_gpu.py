@@ -374,3 +374,76 @@ def test_input_grad_layout_choice_matches_direct(monkeypatch):
     for forced in (True, False):
         monkeypatch.setitem(L._DGRAD_TRANSPOSED, (dy.device.index, 4096, 1001, 768), forced)
         assert rel_err(L.input_grad_mm(buf[:, :1001], w2, buf), ref2) < 1e-2
+
+
+@pytest.mark.parametrize("has_res", [True, False])
+@pytest.mark.parametrize("d", [768, 1280, 1600])
+def test_layer_norm_fused_dropout(d, has_res):
+    """LN(dropout(x) + residual): the mask is recovered from the emitted sum, then forward and
+    backward are compared with PyTorch on that mask (the backward kernel regenerates it)."""
+    from pytorch_distributed_amd.ops.attention import dropout_quantised
+
+    torch.manual_seed(0)
+    rows, p = 512, 0.1
+    pq, scale = dropout_quantised(p)
+    x = torch.randn(rows, d, device=DEV, dtype=torch.bfloat16).requires_grad_()
+    res = torch.randn(rows, d, device=DEV, dtype=torch.bfloat16).requires_grad_() if has_res else None
+    w = (1 + 0.1 * torch.randn(d, device=DEV)).to(torch.bfloat16).requires_grad_()
+    b = (0.1 * torch.randn(d, device=DEV)).to(torch.bfloat16).requires_grad_()
+    y, h = ops.fused_add_layer_norm(x, res, w, b, 1e-5, dropout_p=p, training=True, seed=1234)
+    base = res.detach().float() if has_res else torch.zeros_like(h, dtype=torch.float32)
+    # The mask depends on (seed, row, column) only: read it off a call without residual, where a
+    # dropped element is exactly zero and a kept one is not.
+    _, h0 = ops.fused_add_layer_norm(x.detach(), None, w.detach(), b.detach(), 1e-5, dropout_p=p, training=True, seed=1234)
+    keep = h0 != 0
+    kept = keep.float().mean().item()
+    assert abs(kept - (1 - pq)) < 0.01, kept
+    xr, wr, br = (t.detach().float().requires_grad_() for t in (x, w, b))
+    rr = res.detach().float().requires_grad_() if has_res else None
+    h_ref = xr * keep * scale + (rr if has_res else 0)
+    h_ref_q = h_ref.detach().to(torch.bfloat16).float() + (h_ref - h_ref.detach())  # bf16-rounded value, identity gradient
+    y_ref = torch.nn.functional.layer_norm(h_ref_q, (d,), wr, br, 1e-5)
+    assert rel_err(h, h_ref) < 5e-3 and rel_err(y, y_ref) < 1e-2
+    gy, gh = torch.randn_like(y), torch.randn_like(h)
+    torch.autograd.backward([y, h], [gy, gh])
+    torch.autograd.backward([y_ref, h_ref], [gy.float(), gh.float()])
+    assert rel_err(x.grad, xr.grad) < 1e-2
+    assert (x.grad[~keep] == 0).all()
+    if has_res:
+        assert rel_err(res.grad, rr.grad) < 1e-2
+    assert rel_err(w.grad, wr.grad) < 2e-2 and rel_err(b.grad, br.grad) < 2e-2
+    # same seed -> same mask, another seed -> another mask, eval -> no dropout
+    _, h2 = ops.fused_add_layer_norm(x.detach(), res.detach() if has_res else None, w.detach(), b.detach(), 1e-5,
+                                     dropout_p=p, training=True, seed=1234)
+    _, h3 = ops.fused_add_layer_norm(x.detach(), res.detach() if has_res else None, w.detach(), b.detach(), 1e-5,
+                                     dropout_p=p, training=True, seed=99)
+    _, h4 = ops.fused_add_layer_norm(x.detach(), res.detach() if has_res else None, w.detach(), b.detach(), 1e-5,
+                                     dropout_p=p, training=False)
+    assert torch.equal(h2, h.detach()) and not torch.equal(h3, h.detach())
+    assert rel_err(h4, x.detach().float() + base) < 5e-3
+
+
+def test_gpt2_trains_with_dropout():
+    """All three dropouts of the reference configuration active (p = 0.1): loss falls, and eval
+    mode is deterministic."""
+    from pytorch_distributed_amd.models import MyGPT2LMHeadModel, get_config
+    from pytorch_distributed_amd.optim import FusedAdamW
+
+    cfg = get_config("gpt2", n_layer=2)
+    assert cfg.resid_pdrop == 0.1 and cfg.attn_pdrop == 0.1 and cfg.embd_pdrop == 0.1
+    torch.manual_seed(3)
+    model = MyGPT2LMHeadModel(cfg).to(device=DEV, dtype=torch.bfloat16)
+    ids = torch.randint(0, cfg.vocab_size, (4, 257), device=DEV)
+    opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+    losses = []
+    for _ in range(10):
+        loss = model(ids[:, :-1], ids[:, 1:])
+        loss.backward()
+        opt.step(zero_grad=True)
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 1.0, losses
+    a, b = model(ids[:, :-1], ids[:, 1:]).item(), model(ids[:, :-1], ids[:, 1:]).item()
+    assert a != b  # training mode: fresh masks every call
+    model.eval()
+    with torch.no_grad():
+        assert model(ids[:, :-1], ids[:, 1:]).item() == model(ids[:, :-1], ids[:, 1:]).item()
