@@ -21,9 +21,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kElemsPerThread = 8;                         // two fp32x4 per stream
 constexpr int kChunk = kThreads * kElemsPerThread * 4;     // elements per packed-launch block
-constexpr int kMaxPackedTensors = 24;
-constexpr int kMaxPackedBlocks = 384;
-constexpr int64_t kLargeTensor = int64_t(1) << 20;         // >= this: own grid-stride launch
+constexpr int kMaxPackedTensors = 48;                      // 48 x 56 B of kernel arguments
+constexpr int64_t kMaxPackedBlocks = 65536;                // chunks per packed launch (512 Mi elements)
 
 struct Scalars {
   float decay;      // 1 - lr*wd
@@ -140,17 +139,23 @@ __global__ __launch_bounds__(kThreads) void adamw_flat_kernel(AdamWTensor t, Sca
   adam_range<GradT, kZeroGrad>(t, int64_t(blockIdx.x) * kThreads * 8, t.numel, stride, s);
 }
 
+// One launch covers up to kMaxPackedTensors tensors of any size: workgroup b works on chunk
+// (b - first_block[t]) of tensor t, t found by scanning the (at most 48) block prefix sums.
 struct PackedArgs {
   AdamWTensor tensors[kMaxPackedTensors];
-  int32_t block_chunk[kMaxPackedBlocks];
-  uint8_t block_tensor[kMaxPackedBlocks];
+  int32_t first_block[kMaxPackedTensors + 1];  // prefix sums of the tensors' chunk counts
+  int32_t count;
 };
 
 template <typename GradT, bool kZeroGrad>
 __global__ __launch_bounds__(kThreads) void adamw_packed_kernel(PackedArgs a, Scalars s_in) {
   const Scalars s = resolve(s_in);
-  const AdamWTensor& t = a.tensors[a.block_tensor[blockIdx.x]];
-  const int64_t begin = int64_t(a.block_chunk[blockIdx.x]) * kChunk;
+  const int blk = int(blockIdx.x);
+  int ti = 0;
+#pragma unroll 1
+  while (ti + 1 < a.count && blk >= a.first_block[ti + 1]) ++ti;  // wave-uniform
+  const AdamWTensor& t = a.tensors[ti];
+  const int64_t begin = int64_t(blk - a.first_block[ti]) * kChunk;
   const int64_t end = (begin + kChunk < t.numel) ? begin + kChunk : t.numel;
   adam_range<GradT, kZeroGrad>(t, begin, end, int64_t(kThreads) * 8, s);
 }
@@ -158,10 +163,13 @@ __global__ __launch_bounds__(kThreads) void adamw_packed_kernel(PackedArgs a, Sc
 template <typename GradT, bool kZeroGrad>
 void launch_all(const AdamWTensor* tensors, int n, const Scalars& s, hipStream_t stream) {
   PackedArgs packed;
-  int nt = 0, nb = 0;
+  int nt = 0;
+  int64_t nb = 0;
   auto flush = [&]() {
-    if (nb == 0) return;
-    hipLaunchKernelGGL((adamw_packed_kernel<GradT, kZeroGrad>), dim3(nb), dim3(kThreads), 0, stream,
+    if (nt == 0) return;
+    packed.first_block[nt] = (int32_t)nb;
+    packed.count = nt;
+    hipLaunchKernelGGL((adamw_packed_kernel<GradT, kZeroGrad>), dim3((unsigned)nb), dim3(kThreads), 0, stream,
                        packed, s);
     nt = 0;
     nb = 0;
@@ -169,21 +177,21 @@ void launch_all(const AdamWTensor* tensors, int n, const Scalars& s, hipStream_t
   for (int i = 0; i < n; ++i) {
     const AdamWTensor& t = tensors[i];
     if (t.numel <= 0) continue;
-    if (t.numel >= kLargeTensor) {
+    const int64_t chunks = ceil_div(t.numel, int64_t(kChunk));
+    if (chunks > kMaxPackedBlocks) {
+      // Longer than one packed launch covers (512 Mi elements: the flat shard of a large sharded
+      // model, which is a single tensor anyway): its own grid-stride launch.
+      flush();
       int64_t blocks = ceil_div(t.numel, int64_t(kThreads) * 8);
-      if (blocks > 2048) blocks = 2048;  // 8 blocks per CU, grid-stride beyond that
-      hipLaunchKernelGGL((adamw_flat_kernel<GradT, kZeroGrad>), dim3((unsigned)blocks),
-                         dim3(kThreads), 0, stream, t, s);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL((adamw_flat_kernel<GradT, kZeroGrad>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                         t, s);
       continue;
     }
-    const int chunks = (int)ceil_div(t.numel, kChunk);
     if (nt == kMaxPackedTensors || nb + chunks > kMaxPackedBlocks) flush();
     packed.tensors[nt] = t;
-    for (int c = 0; c < chunks; ++c) {
-      packed.block_tensor[nb] = (uint8_t)nt;
-      packed.block_chunk[nb] = c;
-      ++nb;
-    }
+    packed.first_block[nt] = (int32_t)nb;
+    nb += chunks;
     ++nt;
   }
   flush();

@@ -42,7 +42,7 @@ struct AdamWTensor {
 };
 
 // Decoupled-weight-decay Adam over `n` tensors in as few launches as possible
-// (large tensors get one grid-stride launch each, small ones are packed).
+// (tensors of any size are packed 48 to a launch).
 // If zero_grad is set the gradient is overwritten with zeros once consumed.
 void adamw_step(const AdamWTensor* tensors, int n, DType grad_dtype, const AdamWHyper& hp,
                 bool zero_grad, hipStream_t stream);
