@@ -259,6 +259,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
     kf[ks] = *reinterpret_cast<const bf16x8*>(k_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
     vf[ks] = *reinterpret_cast<const bf16x8*>(v_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
   }
+  // Pin the arrival of the K / V fragments before the tile loop: waited for at their first use
+  // inside it, the wait lands at the loop header, where the compiler cannot tell them from the
+  // next tile's prefetch and waits for every outstanding load before the MFMAs of each tile.
+#pragma unroll
+  for (int ks = 0; ks < kKSteps; ++ks) {
+    asm volatile("" ::"v"(__builtin_bit_cast(u32x4, kf[ks])));
+    asm volatile("" ::"v"(__builtin_bit_cast(u32x4, vf[ks])));
+  }
   f32x16 dk_acc[kDBlocks], dv_acc[kDBlocks];
 #pragma unroll
   for (int i = 0; i < kDBlocks; ++i)
@@ -274,12 +282,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   const int first_tile = (kt * kBM) / kBN;
   const int n_tiles = (T + kBN - 1) / kBN;
 
-  // Threads 0..63 stage -LSE/scale, threads 64..127 stage -delta of the tile's 64 queries.
+  // Threads 0..63 stage -LSE/scale, threads 64..127 stage -delta of the tile's 64 queries. The
+  // load returns the raw value and the arithmetic happens when it is written to LDS a tile later:
+  // computing at load time makes the compiler wait for the load — and, the counter being in
+  // order, for the tile loads issued just before it — at the top of every iteration.
+  const float* rowc_src = tid < 64 ? lse_row : delta_row;
+  const float rowc_mul = tid < 64 ? -inv_scale : -1.f;
   auto load_rowc = [&](int tile) -> float {
     if (tid >= 128) return 0.f;
     int q = tile * kBN + (tid & 63);
     q = q < T ? q : T - 1;
-    return tid < 64 ? -lse_row[q] * inv_scale : -delta_row[q];
+    return rowc_src[q];
   };
   TileStager<D, kBN, kThreads> q_stage, do_stage;
   q_stage.load(q_base, tok_stride, first_tile * kBN, T - 1, tid);
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   float rc_stage = load_rowc(first_tile);
   q_stage.store(smem, tid);
   do_stage.store(smem + kTileBytes, tid);
-  if (tid < 128) rowc[tid] = rc_stage;
+  if (tid < 128) rowc[tid] = rc_stage * rowc_mul;
   __syncthreads();
 
   for (int j = first_tile; j < n_tiles; ++j) {
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       char* nq = smem + (buf ^ 1) * 2 * kTileBytes;
       q_stage.store(nq, tid);
       do_stage.store(nq + kTileBytes, tid);
-      if (tid < 128) rowc[(buf ^ 1) * 128 + tid] = rc_stage;
+      if (tid < 128) rowc[(buf ^ 1) * 128 + tid] = rc_stage * rowc_mul;
     }
     __syncthreads();
   }

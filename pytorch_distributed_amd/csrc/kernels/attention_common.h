@@ -99,6 +99,14 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // Row index, inside a 32-row accumulator tile, of register `reg` for lane-half `h`.
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// max(a, b, c) as one v_max3_f32. The operands must be results of ordinary VALU instructions,
+// NOT of an MFMA: the compiler does not insert the MFMA -> VALU wait states for inline assembly.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 __device__ __forceinline__ float lane_pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float lane_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 

@@ -22,6 +22,8 @@
 // with its index), and consecutive workgroup ids walk (batch, head) so that the
 // query tiles of one head, which share K/V, are 8-aligned apart and therefore
 // land on one XCD's L2 under round-robin dispatch (an affinity hint only).
+#include <type_traits>
+
 #include "attention_common.h"
 #include "pda_kernels.h"
 
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   for (int i = 0; i < kDBlocks; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) o_acc[i][j] = 0.f;
-  float m_run = -INFINITY;  // running row max of the raw (unscaled) scores
+  float m_run = -INFINITY;  // running row max of the scores in exp2 units (score * scale * log2 e)
   float l_run = 0.f;        // this lane's share of the running row sum
   const float c = scale * kLog2e;
 
@@ -88,6 +90,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   const int n_tiles = (q_tile_end + kBN - 1) / kBN;         // key tiles the workgroup visits
   const int wave_last_tile = min(q0 + 31, T - 1) / kBN;     // last tile with an unmasked key for this wave
   const bool wave_active = q0 < T;
+
+  // Pin the arrival of the Q fragments here. Left to their first use inside the tile loop, the
+  // compiler's wait-count bookkeeping at the loop header merges "Q still in flight" (entry) with
+  // "next tile's K/V loads in flight" (back edge) and waits for ALL outstanding loads before the
+  // first MFMAs of every tile, exposing the prefetch latency it was meant to hide.
+#pragma unroll
+  for (int ks = 0; ks < kKSteps; ++ks) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, qf[ks])));
 
   TileStager<D, kBN, kThreads> k_stage, v_stage;
   k_stage.load(k_base, tok_stride, 0, T - 1, tid);
@@ -118,36 +127,54 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
           s_acc[kb] = mfma32(kf, qf[ks], s_acc[kb]);
         }
       }
-      // ---- causal mask on the tiles that straddle the diagonal --------------
+      // ---- scale, causal mask (only on tiles that straddle the diagonal), row maximum --------
+      // The scores are first multiplied by scale * log2(e): exp2 then needs only a subtraction,
+      // and the maximum runs over VALU results: max3() is inline assembly, for which the compiler
+      // inserts no wait states after an MFMA that wrote its operands (fmaxf() on the raw MFMA
+      // results instead costs an extra canonicalising instruction per value).
+      // Masked and unmasked tiles are separate code paths: folded into one, the per-element
+      // compare / select of the mask is evaluated on every tile.
       const int key0 = j * kBN;
-      if (key0 + kBN - 1 > q0) {  // wave-uniform
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = key0 + kb * 32 + acc_row(i, h);
-            if (key > q_row) s_acc[kb][i] = -INFINITY;
-          }
-      }
-      // ---- online softmax (two elements per packed fp32 instruction) -----------
-      float mx = s_acc[0][0];
+      const f32x2 c2 = {c, c};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s_acc[kb][i], s_acc[kb][i + 1]));  // v_max3_f32
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 t = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} * c2;
+          s_acc[kb][i] = t[0];
+          s_acc[kb][i + 1] = t[1];
+        }
+      auto masked_row_max = [&](auto masked) {
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          if (decltype(masked)::value) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              if (key0 + kb * 32 + acc_row(i, h) > q_row) s_acc[kb][i] = -INFINITY;
+              if (key0 + kb * 32 + acc_row(i + 1, h) > q_row) s_acc[kb][i + 1] = -INFINITY;
+            }
+          }
+          m0 = max3(m0, s_acc[0][i], s_acc[0][i + 1]);
+          m1 = max3(m1, s_acc[1][i], s_acc[1][i + 1]);
+        }
+        return fmaxf(m0, m1);
+      };
+      float mx;
+      if (__builtin_expect(key0 + kBN - 1 > q0, 0)) mx = masked_row_max(std::true_type{});  // wave-uniform
+      else mx = masked_row_max(std::false_type{});
       mx = lane_pair_max(mx);
       const float m_new = fmaxf(m_run, mx);  // finite: key 0 is visible to every query
       const bool grew = m_new > m_run;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      const float mc = m_new * c;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
-      const f32x2 c2 = {c, c}, mc2 = {mc, mc};
+      const f32x2 m2 = {m_new, m_new};
       f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-          const f32x2 e = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} * c2 - mc2;
+          const f32x2 e = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} - m2;
           const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
           s_acc[kb][i] = p[0];
           s_acc[kb][i + 1] = p[1];
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
                    pack_bf16x2(o_acc[db][4 * g + 2] * inv_l, o_acc[db][4 * g + 3] * inv_l)};
         *reinterpret_cast<u32x2*>(o_row + db * 32 + 8 * g + 4 * h) = w;
       }
-    if (h == 0) lse_out[(int64_t(b) * H + head) * T + q_row] = m_run * scale + __logf(l_tot);
+    if (h == 0) lse_out[(int64_t(b) * H + head) * T + q_row] = m_run * kLn2 + __logf(l_tot);
   } else {
     (void)lane_pair_sum(l_run);  // keep the cross-lane exchange convergent
   }
