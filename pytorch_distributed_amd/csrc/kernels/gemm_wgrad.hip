@@ -100,14 +100,19 @@ __device__ __forceinline__ bf16x8 join(s16x4 lo, s16x4 hi) {
 // Columns past `cols` (edge tiles of a dimension that is not a multiple of 256) are clamped to the
 // last 16-byte chunk of the row: the duplicate data lands in tile columns whose results are
 // never stored.
-__device__ __forceinline__ void stage_half(const bf16_raw* base, int64_t ld, int row0, int col0, int cols,
-                                           char* tile, int half, int wave, int lane) {
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
+// The per-lane source address of stage 0 is computed once (stage_src); a later stage only adds
+// a wave-uniform byte offset, so the steady-state loop carries no 64-bit multiplies.
+__device__ __forceinline__ const bf16_raw* stage_src(const bf16_raw* base, int64_t ld, int row0, int col0, int cols,
+                                                     int half, int wave, int lane) {
   const int row = 16 * half + 2 * wave + (lane >> 5);
   const int chunk = (lane & 31) ^ ((row & 3) << 2);
   const int col = min(col0 + chunk * 8, cols - 8);
-  const bf16_raw* src = base + int64_t(row0 + row) * ld + col;
+  return base + int64_t(row0 + row) * ld + col;
+}
+
+__device__ __forceinline__ void stage_half(const bf16_raw* src, char* tile, int half, int wave) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
   char* dst = tile + (16 * half + 2 * wave) * kRowBytes;  // wave-uniform
   __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
 }
@@ -164,13 +169,21 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
 
   // Loads of one stage, oldest first: A rows 0-15, B rows 0-15 (k-step 0), then A and B rows
   // 16-31 (k-step 1) — so "all but the last two" of a stage means its k-step 0 has landed.
+  const bf16_raw* a_src[2];
+  const bf16_raw* b_src[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    a_src[half] = stage_src(A, lda, step_lo * kBM, ti * kTile, I, half, wave, lane);
+    b_src[half] = stage_src(B, ldb, step_lo * kBM, tj * kTile, J, half, wave, lane);
+  }
+  const int64_t a_stride = int64_t(kBM) * lda, b_stride = int64_t(kBM) * ldb;  // elements per stage
   auto issue = [&](int t, int slot_idx) {
     char* slot = smem + slot_idx * kStageBytes;
-    const int row0 = (step_lo + t) * kBM;
+    const int64_t ao = int64_t(t) * a_stride, bo = int64_t(t) * b_stride;  // wave-uniform
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      stage_half(A, lda, row0, ti * kTile, I, slot, half, wave, lane);
-      stage_half(B, ldb, row0, tj * kTile, J, slot + kTileBytes, half, wave, lane);
+      stage_half(a_src[half] + ao, slot, half, wave);
+      stage_half(b_src[half] + bo, slot + kTileBytes, half, wave);
     }
   };
 #pragma unroll
