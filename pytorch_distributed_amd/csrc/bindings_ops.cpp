@@ -401,6 +401,8 @@ at::Tensor rope_apply(const at::Tensor& qkv, const at::Tensor& cos, const at::Te
   TORCH_CHECK(cos.scalar_type() == at::kFloat && sin.scalar_type() == at::kFloat && cos.dim() == 2 &&
                   sin.sizes() == cos.sizes() && cos.size(0) >= T && cos.size(1) == D / 2,
               "rope: cos / sin must be float32 [>= T, D/2] tables");
+  TORCH_CHECK(B * T < (int64_t(1) << 31) && T * D < (int64_t(1) << 31) && 3 * num_heads * D < (int64_t(1) << 31),
+              "rope: token count and row length must fit 32-bit indices");
   const c10::DeviceGuard guard(qkv.device());
   at::Tensor out = in_place ? qkv : at::empty_like(qkv);
   pda::rope_apply(dt, qkv.data_ptr(), out.data_ptr(), cos.data_ptr<float>(), sin.data_ptr<float>(), (int)B, (int)T,
