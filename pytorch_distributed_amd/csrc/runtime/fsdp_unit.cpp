@@ -239,9 +239,36 @@ class ShardedUnit {
     unit_done_ = false;
   }
 
+  // Everything the backward did not write must reduce as zeros: parameters that received no
+  // gradient, the alignment gap after a parameter and the tail padding. Zeroing those ranges
+  // here replaces a memset of the whole flat gradient buffer at the start of every backward
+  // (a full extra pass over the unit's gradients per step: sinks and copies overwrite the rest).
+  void zero_unwritten() {
+    at::NoGradGuard ng;
+    int64_t run_begin = -1, run_end = -1;
+    auto add = [&](int64_t b, int64_t e) {
+      if (e <= b) return;
+      if (run_begin >= 0 && b == run_end) {
+        run_end = e;
+        return;
+      }
+      if (run_begin >= 0) full_grad_.narrow(0, run_begin, run_end - run_begin).zero_();
+      run_begin = b;
+      run_end = e;
+    };
+    for (size_t i = 0; i < params_.size(); ++i) {
+      const int64_t begin = offsets_[i], used_end = begin + params_[i].numel();
+      const int64_t next = i + 1 < params_.size() ? offsets_[i + 1] : padded_numel_;
+      if (!grad_written_[i]) add(begin, next);
+      else add(used_end, next);
+    }
+    if (run_begin >= 0) full_grad_.narrow(0, run_begin, run_end - run_begin).zero_();
+  }
+
   void launch_reduce() {
     reduce_launched_ = true;
     if (!grad_allocated_) return;
+    zero_unwritten();
     if (strategy_ == kNoShard) {
       reduced_ = full_grad_;
       if (world_ > 1 || force_collectives_) {
@@ -372,8 +399,7 @@ std::pair<at::Tensor, bool> ShardedUnit::grad_slot(size_t i) {
   std::lock_guard<std::mutex> lock(runtime_->mu_);
   at::NoGradGuard ng;
   if (!grad_allocated_) {
-    allocate_storage(full_grad_, padded_numel_);
-    full_grad_.zero_();
+    allocate_storage(full_grad_, padded_numel_);  // unwritten ranges are zeroed by launch_reduce
     grad_allocated_ = true;
   }
   at::Tensor slot = full_grad_.narrow(0, offsets_[i], params_[i].numel()).view(params_[i].sizes());
@@ -394,8 +420,7 @@ void ShardedUnit::on_grad_ready(size_t i) {
   } else if (g.defined()) {
     at::NoGradGuard ng;
     if (!grad_allocated_) {
-      allocate_storage(full_grad_, padded_numel_);
-      full_grad_.zero_();  // padding (and parameters without a gradient) must reduce as zeros
+      allocate_storage(full_grad_, padded_numel_);  // unwritten ranges are zeroed by launch_reduce
       grad_allocated_ = true;
     }
     at::Tensor slot = full_grad_.narrow(0, offsets_[i], params_[i].numel()).view(params_[i].sizes());

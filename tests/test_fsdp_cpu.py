@@ -87,3 +87,44 @@ def _fsdp_state_dict_roundtrip(rank, world):
 
 def test_fsdp_state_dict_roundtrip():
     run_distributed(_fsdp_state_dict_roundtrip, world=2)
+
+
+def _fsdp_unwritten_ranges(rank, world):
+    """A unit whose flat gradient buffer is only partly written by the backward: one parameter
+    gets no gradient at all, one has a length that leaves an alignment gap, and the tail is
+    padding. Everything unwritten must reduce as zeros, on every step (the buffer is reused)."""
+    import torch.nn as nn
+    from pytorch_distributed_amd.optim import FusedAdamW
+    from pytorch_distributed_amd.parallel import FSDP, ShardingStrategy
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.used = nn.Linear(37, 11)            # 407 + 11 elements: neither is a multiple of the alignment
+            self.unused = nn.Linear(5, 3)             # never called: no gradient
+            self.scale = nn.Parameter(torch.ones(7))  # odd length
+
+        def forward(self, x):
+            return (self.used(x)[:, :7] * self.scale).sum()
+
+    torch.manual_seed(0)
+    ref = Net()
+    model = FSDP(copy.deepcopy(ref), sharding_strategy=ShardingStrategy.FULL_SHARD)
+    opt_ref = FusedAdamW(ref.parameters(), lr=1e-2, weight_decay=0.0)
+    opt = FusedAdamW(model.parameters(), lr=1e-2, weight_decay=0.0)
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 + step)
+        x = torch.randn(4 * world, 37, generator=g)
+        (ref(x) / world).backward()
+        for p in ref.unused.parameters():  # the optimizer below needs a gradient for every parameter
+            p.grad = torch.zeros_like(p)
+        opt_ref.step(zero_grad=True)
+        model(x[4 * rank:4 * rank + 4]).backward()
+        opt.step(zero_grad=True)
+    sd, ref_sd = model.state_dict(), ref.state_dict()
+    for k in ref_sd:
+        torch.testing.assert_close(sd[k], ref_sd[k], rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+
+
+def test_fsdp_unwritten_gradient_ranges_reduce_as_zero():
+    run_distributed(_fsdp_unwritten_ranges, world=2)
