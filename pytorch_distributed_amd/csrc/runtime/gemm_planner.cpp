@@ -224,7 +224,17 @@ class Planner {
     hipEvent_t e0, e1;
     PDA_HIP_CHECK(hipEventCreate(&e0));
     PDA_HIP_CHECK(hipEventCreate(&e1));
-    float best = 1e30f;
+    auto time_us = [&](int i) {
+      PDA_HIP_CHECK(hipEventRecord(e0, stream));
+      for (int r = 0; r < timed_runs; ++r) launch(handle, p, found[i].algo, a, b, out, ws, stream);
+      PDA_HIP_CHECK(hipEventRecord(e1, stream));
+      PDA_HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      PDA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      return ms * 1e3f / timed_runs;
+    };
+    // Pass 1: every valid candidate once.
+    std::vector<std::pair<float, int>> timed;
     for (int i = 0; i < returned; ++i) {
       if (found[i].state != HIPBLAS_STATUS_SUCCESS || found[i].workspaceSize > workspace_limit) continue;
       const float alpha = 1.f, beta = 0.f;
@@ -233,19 +243,29 @@ class Planner {
                                            out.data_ptr(), p.lo, out.data_ptr(), p.lo, &found[i].algo, ws,
                                            workspace_limit, stream);
       if (st != HIPBLAS_STATUS_SUCCESS) continue;
-      PDA_HIP_CHECK(hipEventRecord(e0, stream));
-      for (int r = 0; r < timed_runs; ++r) launch(handle, p, found[i].algo, a, b, out, ws, stream);
-      PDA_HIP_CHECK(hipEventRecord(e1, stream));
-      PDA_HIP_CHECK(hipEventSynchronize(e1));
-      float ms = 0.f;
-      PDA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-      const float us = ms * 1e3f / timed_runs;
+      const float us = time_us(i);
       if (i == 0) p.first_us = us;
-      if (us < best) {
-        best = us;
-        p.chosen = i;
-        p.algo = found[i].algo;
+      timed.emplace_back(us, i);
+    }
+    float best = 1e30f;
+    if (!timed.empty()) {
+      // Pass 2: one short measurement cannot separate candidates a few percent apart (clock and
+      // cache state drift by that much), so the leaders within 5 % of the fastest are re-timed
+      // in alternation and the lowest total wins.
+      std::sort(timed.begin(), timed.end());
+      std::vector<std::pair<float, int>> finalists;
+      for (const auto& t : timed)
+        if (finalists.size() < 4 && t.first <= timed[0].first * 1.05f) finalists.emplace_back(0.f, t.second);
+      if (finalists.size() > 1) {
+        for (int round = 0; round < 3; ++round)
+          for (auto& f : finalists) f.first += time_us(f.second);
+        std::sort(finalists.begin(), finalists.end());
+        best = finalists[0].first / 3.f;
+      } else {
+        best = timed[0].first;
       }
+      p.chosen = finalists[0].second;
+      p.algo = found[p.chosen].algo;
     }
     p.best_us = best;
     (void)hipEventDestroy(e0);
