@@ -106,7 +106,12 @@ def input_grad_mm(dy2: torch.Tensor, weight: torch.Tensor, dy_padded: torch.Tens
     if choice is None:
         if torch.cuda.is_current_stream_capturing():
             return direct()  # cannot time inside a graph capture; decided by an eager step
-        choice = _time_us(transposed) < _time_us(direct)
+        # two alternating measurements of each route; the extra kernel has to pay for itself clearly
+        t_tr = t_di = 0.0
+        for _ in range(2):
+            t_tr += _time_us(transposed)
+            t_di += _time_us(direct)
+        choice = t_tr < 0.99 * t_di
         _DGRAD_TRANSPOSED[key] = choice
     return transposed() if choice else direct()
 
