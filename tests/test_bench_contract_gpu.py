@@ -1,0 +1,56 @@
+"""The benchmark entry point's contract, checked end to end on a GPU: `bench.py` prints exactly one
+JSON line on stdout with the agreed fields, directly and under `torch.distributed.run` (the way a
+multi-GPU run is launched), and `__graft_entry__.smoke()` runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.dist_utils import free_port
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config"}
+
+
+def _run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold the JSON line only, got {len(lines)} lines: {lines[:3]}"
+    return json.loads(lines[0])
+
+
+def _check(res, n_gpus, steps, warmup, parallelism_prefix):
+    assert REQUIRED <= set(res), REQUIRED - set(res)
+    assert res["n_gpus"] == n_gpus and res["steps"] == steps and res["warmup"] == warmup
+    assert res["unit"] == "tokens/s" and res["higher_is_better"] is True and res["scaling"] == "weak"
+    assert res["dtype"] == "bf16" and res["data"] == "synthetic" and res["vs_baseline"] is None
+    cfg = res["config"]
+    assert cfg["model"] == "gpt2" and cfg["seq_len"] == 1024 and cfg["global_batch"] == 8 * n_gpus
+    assert cfg["parallelism"].startswith(parallelism_prefix)
+    tokens_per_step = cfg["global_batch"] * cfg["seq_len"]
+    assert abs(res["value"] - tokens_per_step / (res["ms_per_step"] / 1e3)) < 1e-6 * res["value"]
+
+
+def test_bench_prints_one_json_line():
+    res = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--model", "gpt2",
+                "--batch-per-gpu", "8", "--micro-batch", "8"])
+    _check(res, 1, 3, 1, "single")
+
+
+def test_bench_under_torchrun_uses_the_wrapper():
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1",
+                "--model", "gpt2", "--batch-per-gpu", "8", "--micro-batch", "8", "--wrap-single"])
+    _check(res, 1, 3, 1, "fsdp_full_shard")
+
+
+def test_smoke_entry():
+    proc = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert proc.returncode == 0, proc.stderr[-2000:]
