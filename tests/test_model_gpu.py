@@ -127,3 +127,24 @@ def test_llama_loss_and_grads_match_reference(monkeypatch, name, overrides):
     assert abs(loss.item() - loss_ref.item()) < 2e-2 * loss_ref.item()
     for n, g in grads.items():
         assert rel_err(g, grads_ref[n]) < 6e-2, n
+
+
+def test_full_recompute_reproduces_dropout_masks():
+    """Whole-block recomputation in backward must regenerate the same attention / residual dropout
+    masks as the forward (seeds come from the CPU generator, whose state the checkpoint restores):
+    with equal seeds the gradients equal those of the run that keeps its activations."""
+    cfg = get_config("gpt2", n_layer=2)  # dropout 0.1 everywhere
+    torch.manual_seed(5)
+    base = MyGPT2LMHeadModel(cfg, activation_checkpoint="none").to(device=DEV, dtype=torch.bfloat16)
+    full = MyGPT2LMHeadModel(cfg, activation_checkpoint="full").to(device=DEV, dtype=torch.bfloat16)
+    full.load_state_dict(base.state_dict())
+    ids = torch.randint(0, cfg.vocab_size, (2, 257), device=DEV)
+    grads = []
+    for model in (base, full):
+        torch.manual_seed(77)  # same dropout seeds for both runs
+        loss = model(ids[:, :-1], ids[:, 1:])
+        loss.backward()
+        grads.append((loss.detach().float().item(), {n: p.grad.detach().float() for n, p in model.named_parameters()}))
+    assert grads[0][0] == grads[1][0]
+    for n, g in grads[0][1].items():
+        assert rel_err(grads[1][1][n], g) < 1e-3, n
