@@ -42,6 +42,7 @@ def parse_args():
                     help="data-parallel flavour for --gpus > 1")
     ap.add_argument("--strategy", default="FULL_SHARD", choices=["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"])
     ap.add_argument("--bucket-mb", type=float, default=None)
+    ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--init-device", choices=["auto", "cpu", "gpu"], default="auto",
@@ -114,12 +115,14 @@ def main():
         if args.mode == "ddp":
             from pytorch_distributed_amd.parallel import DDP
             kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
-            model = DDP(model, device_ids=[local_rank], force_collectives=args.wrap_single, **kw)
+            model = DDP(model, device_ids=[local_rank], force_collectives=args.wrap_single,
+                        reduce_fp32=args.reduce_fp32, **kw)
             parallelism = f"ddp{world}"
         else:
             from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
             kw = {} if args.fsdp_unit_blocks is None else {"unit_blocks": args.fsdp_unit_blocks}
-            model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], force_collectives=args.wrap_single, **kw)
+            model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], force_collectives=args.wrap_single,
+                                  reduce_fp32=args.reduce_fp32, **kw)
             parallelism = f"fsdp_{args.strategy.lower()}{world}"
     if args.hip_graph and distributed:
         raise SystemExit("--hip-graph is a single-process mode")

@@ -71,9 +71,9 @@ class ShardedRuntime;
 class ShardedUnit {
  public:
   ShardedUnit(std::vector<at::Tensor> params, c10::intrusive_ptr<c10d::ProcessGroup> pg, int strategy,
-              bool force_collectives)
+              bool force_collectives, bool reduce_fp32)
       : params_(std::move(params)), pg_(std::move(pg)), strategy_(strategy),
-        force_collectives_(force_collectives) {
+        force_collectives_(force_collectives), reduce_fp32_(reduce_fp32) {
     TORCH_CHECK(!params_.empty(), "ShardedUnit: no parameters");
     TORCH_CHECK(strategy_ >= 0 && strategy_ <= 2, "ShardedUnit: bad strategy");
     world_ = pg_ ? pg_->getSize() : 1;
@@ -269,24 +269,33 @@ class ShardedUnit {
     reduce_launched_ = true;
     if (!grad_allocated_) return;
     zero_unwritten();
+    // fp32 reduction of low-precision gradients: the collective runs on a widened copy (twice
+    // the bytes on the wire, no rounding between the ranks' contributions); with an fp32 master
+    // shard the reduced fp32 result is then the optimizer's gradient as it is.
+    const bool communicates = world_ > 1 || force_collectives_;
+    at::Tensor in = full_grad_;
+    if (reduce_fp32_ && communicates && full_grad_.scalar_type() != at::kFloat) {
+      at::NoGradGuard ng;
+      in = full_grad_.to(at::kFloat);
+      reduce_input_ = in;  // kept alive until the collective has been waited for
+    }
     if (strategy_ == kNoShard) {
-      reduced_ = full_grad_;
-      if (world_ > 1 || force_collectives_) {
-        std::vector<at::Tensor> ts{full_grad_};
+      reduced_ = in;
+      if (communicates) {
+        std::vector<at::Tensor> ts{in};
         c10d::AllreduceOptions opts;
         opts.reduceOp = native_avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-        pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, full_grad_.numel(), debug_sequence_, full_grad_, "ShardedUnit");
+        pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, in.numel(), debug_sequence_, in, "ShardedUnit");
         rs_work_ = pg_->allreduce(ts, opts);
-        pda::comm_debug::after(rs_work_, full_grad_);
+        pda::comm_debug::after(rs_work_, in);
         ++num_reductions_;
       }
-    } else if (world_ == 1 && !force_collectives_) {
+    } else if (!communicates) {
       reduced_ = full_grad_.narrow(0, 0, shard_numel_);
     } else {
-      reduced_ = at::empty({shard_numel_}, full_grad_.options());
+      reduced_ = at::empty({shard_numel_}, in.options());
       c10d::ReduceScatterOptions opts;
       opts.reduceOp = native_avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-      at::Tensor in = full_grad_;
       pda::comm_debug::before(pg_, pda::comm_debug::kReduceScatter, in.numel(), debug_sequence_, in, "ShardedUnit");
       rs_work_ = pg_->_reduce_scatter_base(reduced_, in, opts);
       pda::comm_debug::after(rs_work_, in);
@@ -316,6 +325,7 @@ class ShardedUnit {
       g.add_(reduced_);
     }
     reduced_.reset();
+    reduce_input_.reset();
     release_storage(full_grad_);
     grad_allocated_ = false;
     std::fill(grad_written_.begin(), grad_written_.end(), false);
@@ -325,6 +335,8 @@ class ShardedUnit {
   c10::intrusive_ptr<c10d::ProcessGroup> pg_;
   int strategy_;
   bool force_collectives_;
+  bool reduce_fp32_ = false;  // reduce low-precision gradients through an fp32 copy
+  at::Tensor reduce_input_;
   int world_ = 1, rank_ = 0;
   bool native_avg_ = false;
   bool mixed_ = false;
@@ -447,9 +459,9 @@ void ShardedUnit::on_grad_ready(size_t i) {
 
 void bind_fsdp(py::module_& m) {
   py::class_<ShardedUnit, std::shared_ptr<ShardedUnit>>(m, "ShardedUnit")
-      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int, bool>(),
+      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int, bool, bool>(),
            py::arg("params"), py::arg("process_group"), py::arg("strategy"),
-           py::arg("force_collectives") = false)
+           py::arg("force_collectives") = false, py::arg("reduce_fp32") = false)
       .def("unshard", &ShardedUnit::unshard)
       .def("wait_unshard", &ShardedUnit::wait_unshard)
       .def("reshard", &ShardedUnit::reshard)

@@ -51,14 +51,16 @@ struct Bucket {
   std::vector<int64_t> offsets;  // element offset of each parameter inside `flat`
   size_t pending = 0;            // parameters whose gradient has not arrived this pass
   bool launched = false;
+  at::Tensor wide;               // fp32 copy that is reduced instead of `flat` (fp32-reduction option)
   c10::intrusive_ptr<c10d::Work> work;
 };
 
 class GradReducer {
  public:
   GradReducer(std::vector<at::Tensor> params, c10::intrusive_ptr<c10d::ProcessGroup> pg,
-              int64_t bucket_cap_bytes, int64_t first_bucket_bytes, bool force_collectives)
-      : params_(std::move(params)), pg_(std::move(pg)), force_collectives_(force_collectives) {
+              int64_t bucket_cap_bytes, int64_t first_bucket_bytes, bool force_collectives, bool reduce_fp32)
+      : params_(std::move(params)), pg_(std::move(pg)), force_collectives_(force_collectives),
+        reduce_fp32_(reduce_fp32) {
     TORCH_CHECK(!params_.empty(), "GradReducer: no parameters");
     TORCH_CHECK(bucket_cap_bytes > 0 && first_bucket_bytes > 0, "GradReducer: bucket sizes must be positive");
     world_ = pg_ ? pg_->getSize() : 1;
@@ -225,13 +227,22 @@ class GradReducer {
   void launch(Bucket& b) {
     b.launched = true;
     if (world_ == 1 && !force_collectives_) return;
-    std::vector<at::Tensor> tensors{b.flat};
+    // fp32 reduction of low-precision gradients: the bucket is widened, the wide copy is
+    // reduced (twice the bytes on the wire, no rounding between the ranks' contributions) and
+    // narrowed back into the bucket when the pass finishes.
+    at::Tensor payload = b.flat;
+    if (reduce_fp32_ && b.flat.scalar_type() != at::kFloat) {
+      at::NoGradGuard ng;
+      b.wide = b.flat.to(at::kFloat);
+      payload = b.wide;
+    }
+    std::vector<at::Tensor> tensors{payload};
     c10d::AllreduceOptions opts;
     const bool native_avg = backend_ == "nccl";
     opts.reduceOp = native_avg ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-    pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, b.flat.numel(), debug_sequence_, b.flat, "GradReducer");
+    pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, payload.numel(), debug_sequence_, payload, "GradReducer");
     b.work = pg_->allreduce(tensors, opts);
-    pda::comm_debug::after(b.work, b.flat);
+    pda::comm_debug::after(b.work, payload);
     ++num_collectives_;
   }
 
@@ -243,9 +254,12 @@ class GradReducer {
     for (auto& b : buckets_) {
       if (!b.work) continue;
       b.work->wait();  // GPU: current stream waits on the collective's event; CPU: blocks
-      if (!native_avg && world_ > 1) {
-        at::NoGradGuard ng;
-        b.flat.div_((double)world_);
+      at::NoGradGuard ng;
+      at::Tensor& reduced = b.wide.defined() ? b.wide : b.flat;
+      if (!native_avg && world_ > 1) reduced.div_((double)world_);
+      if (b.wide.defined()) {
+        b.flat.copy_(b.wide);
+        b.wide.reset();
       }
       b.work.reset();
     }
@@ -257,6 +271,7 @@ class GradReducer {
   int world_ = 1;
   std::string backend_;
   bool force_collectives_ = false;
+  bool reduce_fp32_ = false;
   bool require_sync_ = true;
   bool in_pass_ = false;
   size_t next_bucket_ = 0;
@@ -274,9 +289,9 @@ class GradReducer {
 
 void bind_reducer(py::module_& m) {
   py::class_<GradReducer, std::shared_ptr<GradReducer>>(m, "GradReducer")
-      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int64_t, int64_t, bool>(),
+      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int64_t, int64_t, bool, bool>(),
            py::arg("params"), py::arg("process_group"), py::arg("bucket_cap_bytes"),
-           py::arg("first_bucket_bytes"), py::arg("force_collectives") = false)
+           py::arg("first_bucket_bytes"), py::arg("force_collectives") = false, py::arg("reduce_fp32") = false)
       .def("set_sync", &GradReducer::set_sync)
       .def("sync_enabled", &GradReducer::sync_enabled)
       .def("remove_hooks", &GradReducer::remove_hooks)

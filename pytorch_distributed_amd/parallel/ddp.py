@@ -40,7 +40,9 @@ def _bucket_slot(p):
 class DDP(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
                  bucket_cap_mb: float = DEFAULT_BUCKET_CAP_MB, first_bucket_mb: float = DEFAULT_FIRST_BUCKET_MB,
-                 broadcast_parameters: bool = True, force_collectives: bool = False):
+                 broadcast_parameters: bool = True, force_collectives: bool = False, reduce_fp32: bool = False):
+        """``reduce_fp32``: all-reduce bf16 gradient buckets through an fp32 copy (twice the bytes on
+        the wire, no rounding between the ranks' contributions); default: the gradient dtype."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("DDP needs an initialised process group (parallel.init_distributed())")
@@ -69,7 +71,7 @@ class DDP(nn.Module):
 
         ext = _ext.require()
         self.reducer = ext.GradReducer(params, self.process_group, int(bucket_cap_mb * 2**20),
-                                       int(first_bucket_mb * 2**20), force_collectives)
+                                       int(first_bucket_mb * 2**20), force_collectives, reduce_fp32)
         for p in params:
             p._pda_grad_is_view = True  # optimizers must zero these in place, never drop them
             # ops.linear / ops.norm add their parameter gradients straight into the bucket view

@@ -57,7 +57,9 @@ class FSDP(nn.Module):
 
     def __init__(self, module: nn.Module, sharding_strategy=ShardingStrategy.FULL_SHARD,
                  process_group=None, forward_prefetch: int = 1, backward_prefetch: int = 1,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, reduce_fp32: bool = False):
+        """``reduce_fp32``: reduce bf16 gradients through an fp32 copy (twice the bytes on the wire,
+        no rounding between the ranks' contributions); the default reduces in the gradient dtype."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("FSDP needs an initialised process group (parallel.init_distributed())")
@@ -92,7 +94,8 @@ class FSDP(nn.Module):
         comm.assert_same_across_ranks([p.numel() for p in mine], "FSDP unit parameter sizes", self.process_group)
 
         ext = _ext.require()
-        self.unit = ext.ShardedUnit(mine, self.process_group, self.sharding_strategy.value, force_collectives)
+        self.unit = ext.ShardedUnit(mine, self.process_group, self.sharding_strategy.value, force_collectives,
+                                    reduce_fp32)
         # Weight matrices hand ops.linear a slice of this unit's flat gradient buffer, so the
         # weight-gradient kernel writes there directly instead of producing a tensor that the
         # gradient hook then copies (one copy kernel per parameter and micro-batch).

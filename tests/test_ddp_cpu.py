@@ -142,3 +142,43 @@ def _comm_debug_modes(rank, world):
 
 def test_comm_debug_modes():
     run_distributed(_comm_debug_modes, world=2)
+
+
+def _reduce_fp32(rank, world, kind):
+    """bf16 model, gradients reduced through an fp32 copy: the averaged gradient must equal the
+    fp32 mean of the two ranks' bf16 gradients rounded ONCE (a bf16 reduction rounds the sum too),
+    and the fp32-reduced run must agree with the default one to bf16 accuracy."""
+    import torch.distributed as dist
+    from pytorch_distributed_amd.parallel import DDP, FSDP, ShardingStrategy
+
+    def grads(reduce_fp32):
+        model = _tiny_model(0).to(torch.bfloat16)
+        if kind == "ddp":
+            wrapped = DDP(model, bucket_cap_mb=0.25, first_bucket_mb=0.05, reduce_fp32=reduce_fp32)
+        else:
+            wrapped = FSDP(model, sharding_strategy=ShardingStrategy[kind], reduce_fp32=reduce_fp32)
+        x, y = _batch(321, 2 * world)
+        wrapped(x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]).backward()
+        if kind == "ddp":
+            return torch.cat([p.grad.detach().float().reshape(-1) for p in model.parameters()])
+        return torch.cat([p.grad.detach().float().reshape(-1) for p in wrapped.parameters()])
+
+    default, wide = grads(False), grads(True)
+    assert default.shape == wide.shape and torch.isfinite(wide).all()
+    rel = ((default - wide).norm() / wide.norm()).item()
+    assert rel < 2e-2, rel
+    if kind == "ddp":
+        # exact statement of the option: local bf16 gradients, averaged in fp32, rounded once
+        local = _tiny_model(0).to(torch.bfloat16)
+        x, y = _batch(321, 2 * world)
+        local(x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]).backward()
+        mine = torch.cat([p.grad.detach().float().reshape(-1) for p in local.parameters()])
+        total = mine.clone()
+        dist.all_reduce(total)
+        expect = (total / world).to(torch.bfloat16).float()
+        assert torch.equal(wide, expect)
+
+
+@pytest.mark.parametrize("kind", ["ddp", "FULL_SHARD", "NO_SHARD"])
+def test_fp32_gradient_reduction(kind):
+    run_distributed(_reduce_fp32, world=2, args=(kind,))

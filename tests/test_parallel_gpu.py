@@ -59,14 +59,16 @@ def _ids(cfg, n, seed=0):
     return [torch.randint(0, cfg.vocab_size, (2, 257), device=DEV, generator=g) for _ in range(n)]
 
 
-def test_ddp_single_gpu_rccl_matches_plain(pg):
+@pytest.mark.parametrize("reduce_fp32", [False, True])
+def test_ddp_single_gpu_rccl_matches_plain(pg, reduce_fp32):
     from pytorch_distributed_amd.parallel import DDP
 
     base, cfg = _model(0)
     ids = _ids(cfg, 8)
     ref_losses = _train(base, base.parameters(), ids)
     model, _ = _model(0)
-    ddp = DDP(model, device_ids=[0], bucket_cap_mb=8, first_bucket_mb=1, force_collectives=True)
+    ddp = DDP(model, device_ids=[0], bucket_cap_mb=8, first_bucket_mb=1, force_collectives=True,
+              reduce_fp32=reduce_fp32)
     losses = _train(ddp, ddp.parameters(), ids, no_sync=ddp.no_sync)
     assert ddp.reducer.num_collectives == 4 * ddp.reducer.num_buckets
     assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-2, (losses, ref_losses)
@@ -74,15 +76,16 @@ def test_ddp_single_gpu_rccl_matches_plain(pg):
         assert (p.float() - q.float()).abs().max().item() < 1e-2, n
 
 
-@pytest.mark.parametrize("strategy", ["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"])
-def test_fsdp_single_gpu_rccl_matches_plain(pg, strategy):
+@pytest.mark.parametrize("strategy,reduce_fp32", [("FULL_SHARD", False), ("SHARD_GRAD_OP", False), ("NO_SHARD", False),
+                                                  ("FULL_SHARD", True), ("NO_SHARD", True)])
+def test_fsdp_single_gpu_rccl_matches_plain(pg, strategy, reduce_fp32):
     from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
 
     base, cfg = _model(1)
     ids = _ids(cfg, 8, seed=1)
     ref_losses = _train(base, base.parameters(), ids)
     model, _ = _model(1)
-    fsdp = fsdp_wrap_gpt(model, ShardingStrategy[strategy], force_collectives=True)
+    fsdp = fsdp_wrap_gpt(model, ShardingStrategy[strategy], force_collectives=True, reduce_fp32=reduce_fp32)
     losses = _train(fsdp, fsdp.parameters(), ids, no_sync=fsdp.no_sync)
     assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-2, (losses, ref_losses)
     sd, ref_sd = fsdp.state_dict(), base.state_dict()

@@ -17,17 +17,18 @@ from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
-def setup_ddp_model(model, device, bucket_cap_mb=None):
+def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False):
     """``model`` (already on ``device``) wrapped in DDP."""
     kw = {} if bucket_cap_mb is None else {"bucket_cap_mb": bucket_cap_mb}
     ids = [device.index] if device.type == "cuda" else None
-    return DDP(model, device_ids=ids, **kw)
+    return DDP(model, device_ids=ids, reduce_fp32=reduce_fp32, **kw)
 
 
 def main():
     ap = cli.add_common_args(argparse.ArgumentParser(description=__doc__))
     ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size (default 64 MiB)")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"])
+    ap.add_argument("--reduce-fp32", action="store_true", help="all-reduce bf16 gradients through an fp32 copy")
     args = ap.parse_args()
     rank, world, device = init_distributed(args.backend)
     dtype = cli.resolve_dtype(args, device)
@@ -36,7 +37,7 @@ def main():
               f"Micro batch size per rank: {args.micro_batch_size}\nWorld size: {world}\n"
               f"Sequence length: {args.sequence_length}\nMax steps: {args.max_steps}")
     model, cfg = cli.build_model(args, device, dtype)  # same seed on every rank
-    model = setup_ddp_model(model, device, args.bucket_mb)
+    model = setup_ddp_model(model, device, args.bucket_mb, args.reduce_fp32)
     if rank == 0:
         print(f"Model wrapped with DDP ({model.reducer.num_buckets} gradient buckets)")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)

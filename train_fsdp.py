@@ -17,15 +17,15 @@ from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
-def setup_fsdp_model(model, device, sharding_strategy_name="FULL_SHARD", unit_blocks=1):
+def setup_fsdp_model(model, device, sharding_strategy_name="FULL_SHARD", unit_blocks=1, reduce_fp32=False):
     """Per-block wrapping plus the root unit (the reference's layout when ``unit_blocks == 1``)."""
     model = model.to(device)
     strategy = ShardingStrategy[sharding_strategy_name]
     if unit_blocks == 1:
         for i, block in enumerate(model.transformer.h):
-            model.transformer.h[i] = FSDP(block, sharding_strategy=strategy)
-        return FSDP(model, sharding_strategy=strategy)
-    return fsdp_wrap_gpt(model, strategy, unit_blocks=unit_blocks)
+            model.transformer.h[i] = FSDP(block, sharding_strategy=strategy, reduce_fp32=reduce_fp32)
+        return FSDP(model, sharding_strategy=strategy, reduce_fp32=reduce_fp32)
+    return fsdp_wrap_gpt(model, strategy, unit_blocks=unit_blocks, reduce_fp32=reduce_fp32)
 
 
 def main():
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--strategy", type=str, default="FULL_SHARD",
                     choices=["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"], help="FSDP sharding strategy")
     ap.add_argument("--fsdp-unit-blocks", type=int, default=1)
+    ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"])
     ap.add_argument("--sharded-checkpoint", default=None,
                     help="directory: also write a per-rank sharded checkpoint at the end of training")
@@ -44,7 +45,7 @@ def main():
               f"Global batch size: {args.global_batch_size}\nMicro batch size per rank: {args.micro_batch_size}\n"
               f"World size: {world}\nSequence length: {args.sequence_length}\nMax steps: {args.max_steps}")
     model, cfg = cli.build_model(args, device, dtype)
-    model = setup_fsdp_model(model, device, args.strategy, args.fsdp_unit_blocks)
+    model = setup_fsdp_model(model, device, args.strategy, args.fsdp_unit_blocks, args.reduce_fp32)
     if rank == 0:
         print(f"Model wrapped with FSDP ({args.strategy})")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
