@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
     ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",
-                    help="single GPU: record the whole optimizer step into a HIP graph and replay it")
+                    help="single GPU, experimental: record the whole optimizer step into a HIP graph and replay it")
     ap.add_argument("--wrap-single", action="store_true",
                     help="with --gpus 1: still wrap in DDP/FSDP and force the RCCL collectives (rehearsal)")
     return ap.parse_args()
