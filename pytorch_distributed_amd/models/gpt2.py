@@ -145,7 +145,7 @@ class MyGPT2Model(nn.Module):
         positions = torch.arange(seq_len, device=input_ids.device)
         # Embedding dropout, like every residual dropout below, is applied inside the LayerNorm
         # kernel that consumes the tensor (`delta_pdrop`).
-        delta = self.wte(input_ids) + self.wpe(positions)
+        delta = ops.embedding(input_ids, self.wte.weight) + self.wpe(positions)
         pdrop = self.drop.p
         residual = None
         full_recompute = (self.enable_activation_checkpoint and self.training

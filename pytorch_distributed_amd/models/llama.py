@@ -154,7 +154,7 @@ class LlamaModel(nn.Module):
         if c is None or c[0].device != input_ids.device or c[0].shape[0] < T:
             self._rope_cache = rope_tables(self.config.n_ctx, self.config.head_dim, self.config.rope_theta,
                                            input_ids.device)
-        delta, residual = self.wte(input_ids), None
+        delta, residual = ops.embedding(input_ids, self.wte.weight), None
         full = self.activation_checkpoint == "full" and self.training
         for block in self.h:
             if full:
