@@ -1,10 +1,11 @@
-"""Headline benchmark: GPT training throughput (tokens/s, MFU) on N MI355X GPUs.
+"""Headline benchmark: GPT training throughput (tokens/s, MFU) on N MI355X GPUs, DDP and FSDP.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N > 1 launched through
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``, one rank per
-GPU over RCCL). W untimed warm-up steps, then exactly K optimizer steps timed between
-barrier + device-synchronise pairs; the maximum over ranks is reported and rank 0 prints ONE
-JSON line.
+Contract: ``python bench.py --gpus N --steps K --warmup W``. With N > 1 and no launcher
+environment the script starts the N ranks itself (``python -m torch.distributed.run`` as a CHILD
+process, before this process has touched a GPU), relays the result line and exits with the child's
+code; under ``torch.distributed.run`` (``WORLD_SIZE`` set) it is one of the ranks. W untimed warm-up
+steps, then exactly K optimizer steps timed between barrier + device-synchronise pairs; the maximum
+over ranks is reported and rank 0 prints ONE JSON line.
 
 Workload (the reference's assignment-1 configuration, weak-scaled): GPT-2 Large
 (774 M parameters), sequence length 1024, 32 sequences per GPU per optimizer step
@@ -13,23 +14,31 @@ assignments/assignment1/train_baseline.py:24-31), AdamW lr 3e-4 wd 0.1, bf16 com
 master weights and optimizer state, synthetic uniform-random tokens, random-init weights,
 dropout 0. One step = every micro-batch's forward + backward, gradient synchronisation and
 the optimizer update.
+
+Modes (``--mode``): ``single`` (one GPU, no wrapper), ``ddp``, ``fsdp`` (``--strategy``), ``both`` =
+DDP then FSDP measured back to back in the same job. Defaults: ``single`` for one GPU, ``both`` for
+several; with ``both`` the headline ``value`` is FSDP's and the line carries a ``modes`` table with
+the DDP and FSDP numbers side by side (the reference's DDP-versus-FSDP comparison:
+assignments/assignment1/train_ddp.py:39-51, train_fsdp.py:42-83). Collectives run on the
+framework's own RCCL communicator (``--comm native``) or, for comparison, through a
+torch.distributed process group behind the same interface (``--comm c10d``).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -38,30 +47,61 @@ def parse_args():
     ap.add_argument("--seq-len", type=int, default=1024)
     ap.add_argument("--batch-per-gpu", type=int, default=32, help="sequences per GPU per optimizer step")
     ap.add_argument("--micro-batch", type=int, default=32, help="sequences per forward/backward")
-    ap.add_argument("--mode", choices=["fsdp", "ddp"], default="fsdp",
-                    help="data-parallel flavour for --gpus > 1")
+    ap.add_argument("--mode", choices=["auto", "single", "fsdp", "ddp", "both"], default="auto",
+                    help="auto = single on one GPU, both (DDP then FSDP) on several")
     ap.add_argument("--strategy", default="FULL_SHARD", choices=["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"])
-    ap.add_argument("--bucket-mb", type=float, default=None)
+    ap.add_argument("--bucket-mb", type=float, default=None, help="DDP bucket size (default: measured at start-up)")
+    ap.add_argument("--ddp-decompose", choices=["auto", "on", "off"], default="auto",
+                    help="reduce DDP buckets as reduce-scatter + all-gather (auto: measured at start-up)")
     ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
-    ap.add_argument("--fsdp-unit-blocks", type=int, default=None)
+    ap.add_argument("--fsdp-unit-blocks", type=int, default=None,
+                    help="transformer blocks per sharding unit (default: measured at start-up)")
+    ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
+    ap.add_argument("--comm", choices=["native", "c10d"], default="native",
+                    help="native = the framework's RCCL communicator; c10d = a torch.distributed group behind the same interface")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--init-device", choices=["auto", "cpu", "gpu"], default="auto",
                     help="construct the model on the host (then move) or directly on the GPU; auto = GPU above 1e9 parameters")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="attention / residual / embedding dropout probability (GPT-2 configurations; 0 = off)")
+    ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="selective")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
     ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",
                     help="single GPU, experimental: record the whole optimizer step into a HIP graph and replay it")
     ap.add_argument("--wrap-single", action="store_true",
                     help="with --gpus 1: still wrap in DDP/FSDP and force the RCCL collectives (rehearsal)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """Parent mode: start ``args.gpus`` ranks as a child job and relay its single result line.
+    Nothing in this process has initialised a GPU (no HIP call happens before this point)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
     # The contract is ONE JSON line on stdout. Libraries print banners of their own there
-    # (RCCL's version block, process-group messages), so everything written to fd 1 while the
+    # (RCCL's version block, start-up messages), so everything written to fd 1 while the
     # benchmark runs is sent to stderr and the result line goes to the real stdout at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -70,16 +110,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
 
-    import torch.distributed as dist
     from pytorch_distributed_amd import MI355X_PEAK_BF16_FLOPS
     from pytorch_distributed_amd.data import SyntheticTokenLoader
-    from pytorch_distributed_amd.models import MyGPT2LMHeadModel, get_config
+    from pytorch_distributed_amd.models import LlamaForCausalLM, MyGPT2LMHeadModel, get_config, init_on_device
     from pytorch_distributed_amd.optim import FusedAdamW
+    from pytorch_distributed_amd.parallel import autotune, comm
     from pytorch_distributed_amd.utils.flops import model_flops_per_token
 
     torch.cuda.set_device(local_rank)
@@ -88,113 +130,161 @@ def main():
     if not args.no_tuned_gemms:
         from pytorch_distributed_amd.tuning import enable_tuned_gemms
         tuned = enable_tuned_gemms()
-    distributed = world > 1 or args.wrap_single
+
+    mode = args.mode
+    if mode == "auto":
+        mode = "both" if world > 1 else ("fsdp" if args.wrap_single else "single")
+    distributed = mode != "single"
+    if args.hip_graph and distributed:
+        raise SystemExit("--hip-graph is a single-process mode")
+    if args.batch_per_gpu % args.micro_batch != 0:
+        raise SystemExit("--batch-per-gpu must be a multiple of --micro-batch")
+    accum = args.batch_per_gpu // args.micro_batch
+
+    policy = None
     if distributed:
-        from pytorch_distributed_amd.parallel import init_distributed
-        init_distributed(backend="nccl")
+        comm.init_distributed(backend="rccl" if args.comm == "native" else "c10d", timeout_s=300.0)
+        if world > 1 and not args.no_comm_autotune:
+            policy = autotune.tune(device=device, verbose=True)
 
     cfg = get_config(args.model).without_dropout()
     if args.dropout > 0 and hasattr(cfg, "attn_pdrop"):
         cfg.attn_pdrop = cfg.resid_pdrop = cfg.embd_pdrop = args.dropout
-    torch.manual_seed(42)
-    import contextlib
-    from pytorch_distributed_amd.models import LlamaForCausalLM, init_on_device
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    cls = LlamaForCausalLM if hasattr(cfg, "intermediate_size") else MyGPT2LMHeadModel
+    is_llama = hasattr(cfg, "intermediate_size")
+    cls = LlamaForCausalLM if is_llama else MyGPT2LMHeadModel
     on_gpu = args.init_device == "gpu"
     if args.init_device == "auto":
         with init_on_device("meta"):
             on_gpu = sum(p.numel() for p in cls(cfg).parameters()) > 1e9
-    torch.cuda.manual_seed(42)
-    with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
-        model = cls(cfg)
-    model = model.to(device=device, dtype=dtype)
+    fpt = model_flops_per_token(_cfg_holder(cfg), args.seq_len)
 
-    parallelism = "single"
-    if distributed:
-        if args.mode == "ddp":
-            from pytorch_distributed_amd.parallel import DDP
-            kw = {} if args.bucket_mb is None else {"bucket_cap_mb": args.bucket_mb}
-            model = DDP(model, device_ids=[local_rank], force_collectives=args.wrap_single,
-                        reduce_fp32=args.reduce_fp32, **kw)
-            parallelism = f"ddp{world}"
-        else:
-            from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
-            kw = {} if args.fsdp_unit_blocks is None else {"unit_blocks": args.fsdp_unit_blocks}
-            model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], force_collectives=args.wrap_single,
-                                  reduce_fp32=args.reduce_fp32, **kw)
-            parallelism = f"fsdp_{args.strategy.lower()}{world}"
-    if args.hip_graph and distributed:
-        raise SystemExit("--hip-graph is a single-process mode")
-    optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1, capturable=args.hip_graph)
-
-    if args.batch_per_gpu % args.micro_batch != 0:
-        raise SystemExit("--batch-per-gpu must be a multiple of --micro-batch")
-    accum = args.batch_per_gpu // args.micro_batch
-    loader = iter(SyntheticTokenLoader(args.micro_batch, args.seq_len, cfg.vocab_size, device, seed=1234 + rank))
-    model.train()
-
-    def one_step():
-        for i in range(accum):
-            inputs, targets = next(loader)
-            last = i == accum - 1
-            if distributed and not last:
-                with model.no_sync():
-                    (model(inputs, targets) / accum).backward()
-            else:
-                (model(inputs, targets) / accum).backward()
-        optimizer.step(zero_grad=True)
-
-    if args.hip_graph:
-        from pytorch_distributed_amd.utils.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(model, optimizer, args.micro_batch, args.seq_len, accum, warmup_steps=2)
-
-        def one_step():  # noqa: F811 - replaces the eager step above
-            xs, ys = zip(*(next(loader) for _ in range(accum)))
-            graphed(torch.stack(xs), torch.stack(ys))
-
-        for _ in range(3):  # 2 eager warm-up steps + the capture happen before the timed region
-            one_step()
+    def build_model():
+        import contextlib
+        torch.manual_seed(42)
+        torch.cuda.manual_seed(42)
+        kw = {} if is_llama else {"activation_checkpoint": args.activation_checkpoint}
+        with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
+            m = cls(cfg, **kw)
+        return m.to(device=device, dtype=dtype)
 
     def fence():
         if distributed:
-            dist.barrier()
+            comm.barrier()
         torch.cuda.synchronize(device)
+        if distributed:
+            comm.barrier()
 
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(kind: str) -> dict:
+        """Builds the model wrapped as ``kind`` and times K steps. Returns the result fields."""
+        model = build_model()
+        detail = {}
+        if distributed and args.dtype == "bf16":
+            # GEMM algorithm / layout decisions: measured once on the bare model, rank 0's adopted by all
+            from pytorch_distributed_amd.parallel import plan_sync
+            plan_sync.plan_gemms(model, args.micro_batch, args.seq_len, cfg.vocab_size)
+        if kind == "ddp":
+            from pytorch_distributed_amd.parallel import DDP
+            decompose = {"auto": None, "on": True, "off": False}[args.ddp_decompose]
+            model = DDP(model, device_ids=[local_rank], force_collectives=args.wrap_single,
+                        reduce_fp32=args.reduce_fp32, bucket_cap_mb=args.bucket_mb, decompose=decompose)
+            parallelism = f"ddp{world}"
+            detail = {"bucket_mb": model.bucket_cap_mb, "decompose": model.decompose,
+                      "buckets": model.reducer.num_buckets}
+        elif kind == "fsdp":
+            from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
+            unit_blocks = args.fsdp_unit_blocks
+            if unit_blocks is None:
+                blocks = model.transformer.h if hasattr(model, "transformer") else model.model.layers
+                block_bytes = sum(p.numel() * p.element_size() for p in blocks[0].parameters())
+                unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
+            model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], unit_blocks=unit_blocks,
+                                  force_collectives=args.wrap_single, reduce_fp32=args.reduce_fp32)
+            parallelism = f"fsdp_{args.strategy.lower()}{world}"
+            detail = {"unit_blocks": unit_blocks}
+        else:
+            parallelism = "single"
+        optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1, capturable=args.hip_graph)
+        loader = iter(SyntheticTokenLoader(args.micro_batch, args.seq_len, cfg.vocab_size, device, seed=1234 + rank))
+        model.train()
 
-    global_batch = args.batch_per_gpu * world
-    tokens_per_step = global_batch * args.seq_len
-    tps = tokens_per_step * args.steps / elapsed
-    fpt = model_flops_per_token(_cfg_holder(cfg), args.seq_len)
-    mfu = tps * fpt / (world * MI355X_PEAK_BF16_FLOPS)
+        def one_step():
+            for i in range(accum):
+                inputs, targets = next(loader)
+                if distributed and i < accum - 1:
+                    with model.no_sync():
+                        (model(inputs, targets) / accum).backward()
+                else:
+                    (model(inputs, targets) / accum).backward()
+            optimizer.step(zero_grad=True)
+
+        if args.hip_graph:
+            from pytorch_distributed_amd.utils.graphs import GraphedTrainStep
+            graphed = GraphedTrainStep(model, optimizer, args.micro_batch, args.seq_len, accum, warmup_steps=2)
+
+            def one_step():  # noqa: F811 - replaces the eager step above
+                xs, ys = zip(*(next(loader) for _ in range(accum)))
+                graphed(torch.stack(xs), torch.stack(ys))
+
+            for _ in range(3):  # 2 eager warm-up steps + the capture happen before the timed region
+                one_step()
+
+        for _ in range(args.warmup):
+            one_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if distributed and world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            comm.all_reduce(t, "max")
+            elapsed = float(t.item())
+        tokens_per_step = args.batch_per_gpu * world * args.seq_len
+        tps = tokens_per_step * args.steps / elapsed
+        out = {"parallelism": parallelism, "value": tps, "ms_per_step": 1e3 * elapsed / args.steps,
+               "mfu": tps * fpt / (world * MI355X_PEAK_BF16_FLOPS), "tflops_per_gpu": tps * fpt / world / 1e12,
+               "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2**30, **detail}
+        del model, optimizer, loader, one_step
+        import gc
+        gc.collect()
+        torch.cuda.synchronize(device)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(device)
+        return out
+
+    kinds = {"single": ["single"], "ddp": ["ddp"], "fsdp": ["fsdp"], "both": ["ddp", "fsdp"]}[mode]
+    results = {k: measure(k) for k in kinds}
+    head = results[kinds[-1]]  # FSDP when both were measured
+
     if rank == 0:
-        result_line = json.dumps({
-            "metric": f"tokens/sec (whole job), {_pretty(args.model)} training, {args.dtype}", "value": tps, "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        global_batch = args.batch_per_gpu * world
+        config = {"model": args.model, "global_batch": global_batch, "micro_batch": args.micro_batch,
+                  "grad_accum": accum, "seq_len": args.seq_len, "parallelism": head["parallelism"],
+                  "dropout": args.dropout, "activation_checkpoint": args.activation_checkpoint,
+                  "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
+                  "flops_per_token": fpt, "tuned_gemm_table": tuned, "hip_graph": bool(args.hip_graph)}
+        if distributed:
+            c = comm.get_communicator()
+            config["comm_backend"] = c.backend
+            if policy is not None:
+                config["comm_policy"] = {"ddp_bucket_mb": policy.ddp_bucket_mb, "ddp_decompose": policy.ddp_decompose,
+                                         "fsdp_unit_mb": policy.fsdp_unit_mb, "source": policy.source,
+                                         "fits_us_GBps": {k: [round(a * 1e6, 1), round(b / 1e9, 1)]
+                                                          for k, (a, b) in policy.fits.items()}}
+        line = {
+            "metric": f"tokens/sec (whole job), {_pretty(args.model)} training, {args.dtype}", "value": head["value"],
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "mfu": mfu, "tflops_per_gpu": tps * fpt / world / 1e12,
-            "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2**30,
-            "config": {"model": args.model, "global_batch": global_batch, "micro_batch": args.micro_batch,
-                       "grad_accum": accum, "seq_len": args.seq_len, "parallelism": parallelism,
-                       "dropout": args.dropout,
-                       "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
-                       "flops_per_token": fpt, "tuned_gemm_table": tuned, "hip_graph": bool(args.hip_graph)},
-        })
+            "mfu": head["mfu"], "tflops_per_gpu": head["tflops_per_gpu"], "peak_mem_gb": head["peak_mem_gb"],
+            "config": config,
+        }
+        if len(results) > 1 or distributed:
+            line["modes"] = results
         sys.stdout.flush()
-        os.write(real_stdout, (result_line + "\n").encode())
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if args.planner_stats and rank == 0:
         from pytorch_distributed_amd import _ext
         st = _ext.require().gemm_planner_stats()
@@ -202,7 +292,8 @@ def main():
             print("planner m=%d n=%d k=%d ta=%d tb=%d ep=%d candidates=%d chosen=%d first=%.1fus best=%.1fus"
                   % tuple(row), file=sys.stderr)
     if distributed:
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.shutdown()
 
 
 def _pretty(model_name: str) -> str:

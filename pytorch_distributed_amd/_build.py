@@ -133,9 +133,9 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
         link = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(TARGET), *objs,
                 f"-L{torch_lib}", f"-Wl,-rpath,{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu",
                 "-ltorch_hip", "-ltorch", "-ltorch_python",
-                # the hipBLASLt that PyTorch itself loaded (linking /opt/rocm's copy would pull a second
-                # HIP runtime into the process)
-                str(Path(torch_lib) / "libhipblaslt.so"), "-lpthread"]
+                # the hipBLASLt and RCCL that PyTorch itself loaded (linking /opt/rocm's copies would
+                # pull a second HIP runtime into the process)
+                str(Path(torch_lib) / "libhipblaslt.so"), str(Path(torch_lib) / "librccl.so"), "-lpthread"]
         if verbose:
             print("[build]", " ".join(link), flush=True)
         proc = subprocess.run(link, capture_output=True, text=True)

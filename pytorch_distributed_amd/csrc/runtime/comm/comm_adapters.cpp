@@ -1,0 +1,216 @@
+// Two thin Communicator implementations that wrap something else:
+//
+//   C10dCommunicator       adapter around a torch.distributed process group a caller already
+//                          owns (`DDP(model, process_group=pg)`), so code written against
+//                          torch's groups keeps working; the framework's own bootstrap never
+//                          creates one.
+//   RecordingCommunicator  decorator: forwards to an inner communicator and keeps a log of
+//                          (kind, elements, queue) per collective, in issue order. Tests assert
+//                          exact collective sequences on it (prefetch order, "no_sync issues
+//                          nothing"), and the trace tools use the log to label collectives.
+#include "communicator.h"
+
+#include <c10/util/Exception.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+
+namespace pda {
+namespace comm {
+
+namespace {
+
+class C10dWork final : public Work {
+ public:
+  explicit C10dWork(c10::intrusive_ptr<c10d::Work> w, std::vector<at::Tensor> keep)
+      : work_(std::move(w)), keep_(std::move(keep)) {}
+  void wait() override {
+    if (work_) work_->wait();
+  }
+  void synchronize() override {
+    if (!work_) return;
+    work_->wait();
+    work_->synchronize();
+  }
+  bool completed() override { return !work_ || work_->isCompleted(); }
+
+ private:
+  c10::intrusive_ptr<c10d::Work> work_;
+  std::vector<at::Tensor> keep_;
+};
+
+class C10dCommunicator final : public Communicator {
+ public:
+  explicit C10dCommunicator(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {
+    TORCH_CHECK(pg_, "C10dCommunicator: null process group");
+    name_ = pg_->getBackendName();
+  }
+  int rank() const override { return pg_->getRank(); }
+  int world() const override { return pg_->getSize(); }
+  std::string backend() const override { return "c10d:" + name_; }
+  bool on_gpu() const override { return name_ == "nccl"; }
+
+  std::shared_ptr<Work> all_reduce(const at::Tensor& t, RedOp op, Queue) override {
+    check_collective_args("all_reduce", t, t, 1, t.is_cuda());
+    count(Kind::kAllReduce, t);
+    std::vector<at::Tensor> ts{t};
+    c10d::AllreduceOptions opts;
+    const bool scale = op == RedOp::kAvg && name_ != "nccl";  // gloo has no AVG
+    opts.reduceOp = op == RedOp::kMax ? c10d::ReduceOp::MAX
+                                      : (op == RedOp::kAvg && !scale ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM);
+    auto w = pg_->allreduce(ts, opts);
+    if (scale) {
+      w->wait();
+      at::NoGradGuard ng;
+      at::Tensor(t).div_((double)world());
+      return std::make_shared<CompletedWork>();
+    }
+    return std::make_shared<C10dWork>(std::move(w), std::vector<at::Tensor>{t});
+  }
+
+  std::shared_ptr<Work> all_gather(const at::Tensor& out, const at::Tensor& in, Queue) override {
+    check_collective_args("all_gather", out, in, world(), out.is_cuda());
+    count(Kind::kAllGather, out);
+    at::Tensor o = out, i = in;
+    return std::make_shared<C10dWork>(pg_->_allgather_base(o, i), std::vector<at::Tensor>{out, in});
+  }
+
+  std::shared_ptr<Work> reduce_scatter(const at::Tensor& out, const at::Tensor& in, RedOp op, Queue) override {
+    check_collective_args("reduce_scatter", in, out, world(), out.is_cuda());
+    count(Kind::kReduceScatter, in);
+    at::Tensor o = out, i = in;
+    c10d::ReduceScatterOptions opts;
+    const bool scale = op == RedOp::kAvg && name_ != "nccl";
+    opts.reduceOp = op == RedOp::kMax ? c10d::ReduceOp::MAX
+                                      : (op == RedOp::kAvg && !scale ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM);
+    auto w = pg_->_reduce_scatter_base(o, i, opts);
+    if (scale) {
+      w->wait();
+      at::NoGradGuard ng;
+      o.div_((double)world());
+      return std::make_shared<CompletedWork>();
+    }
+    return std::make_shared<C10dWork>(std::move(w), std::vector<at::Tensor>{out, in});
+  }
+
+  std::shared_ptr<Work> broadcast(const at::Tensor& t, int root, Queue) override {
+    count(Kind::kBroadcast, t);
+    std::vector<at::Tensor> ts{t};
+    c10d::BroadcastOptions opts;
+    opts.rootRank = root;
+    return std::make_shared<C10dWork>(pg_->broadcast(ts, opts), std::vector<at::Tensor>{t});
+  }
+
+  void barrier() override { pg_->barrier()->wait(); }
+  void abort() override { pg_->abort(); }
+
+  std::vector<std::string> exchange(const std::string& mine) override {
+    if (world() <= 1) return {mine};
+    // Two rounds over the group: lengths, then padded payloads.
+    const auto dev = on_gpu() ? at::Device(at::kCUDA) : at::Device(at::kCPU);
+    auto gather = [&](const at::Tensor& local) {
+      std::vector<at::Tensor> outs;
+      for (int r = 0; r < world(); ++r) outs.push_back(at::empty_like(local));
+      std::vector<std::vector<at::Tensor>> lists{outs};
+      std::vector<at::Tensor> ins{local};
+      pg_->allgather(lists, ins)->wait();
+      return lists[0];
+    };
+    at::Tensor len = at::tensor({(int64_t)mine.size()}, at::TensorOptions().dtype(at::kLong)).to(dev);
+    auto lens = gather(len);
+    int64_t longest = 0;
+    for (auto& l : lens) longest = std::max(longest, l.cpu().item<int64_t>());
+    at::Tensor payload = at::zeros({longest}, at::TensorOptions().dtype(at::kByte));
+    std::memcpy(payload.data_ptr(), mine.data(), mine.size());
+    auto all = gather(payload.to(dev));
+    std::vector<std::string> out;
+    for (int r = 0; r < world(); ++r) {
+      at::Tensor c = all[r].cpu();
+      out.emplace_back(static_cast<const char*>(c.data_ptr()), (size_t)lens[r].cpu().item<int64_t>());
+    }
+    return out;
+  }
+
+ private:
+  c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+  std::string name_;
+};
+
+}  // namespace
+
+struct RecordedCall {
+  int kind;
+  int64_t numel;
+  int queue;
+};
+
+class RecordingCommunicator final : public Communicator {
+ public:
+  explicit RecordingCommunicator(std::shared_ptr<Communicator> inner) : inner_(std::move(inner)) {
+    TORCH_CHECK(inner_, "RecordingCommunicator: null inner communicator");
+  }
+  int rank() const override { return inner_->rank(); }
+  int world() const override { return inner_->world(); }
+  std::string backend() const override { return "recording:" + inner_->backend(); }
+  bool on_gpu() const override { return inner_->on_gpu(); }
+  bool aborted() const override { return inner_->aborted(); }
+
+  std::shared_ptr<Work> all_reduce(const at::Tensor& t, RedOp op, Queue q) override {
+    note(Kind::kAllReduce, t.numel(), q, t);
+    return inner_->all_reduce(t, op, q);
+  }
+  std::shared_ptr<Work> all_gather(const at::Tensor& out, const at::Tensor& in, Queue q) override {
+    note(Kind::kAllGather, out.numel(), q, out);
+    return inner_->all_gather(out, in, q);
+  }
+  std::shared_ptr<Work> reduce_scatter(const at::Tensor& out, const at::Tensor& in, RedOp op, Queue q) override {
+    note(Kind::kReduceScatter, in.numel(), q, in);
+    return inner_->reduce_scatter(out, in, op, q);
+  }
+  std::shared_ptr<Work> broadcast(const at::Tensor& t, int root, Queue q) override {
+    note(Kind::kBroadcast, t.numel(), q, t);
+    return inner_->broadcast(t, root, q);
+  }
+  void barrier() override { inner_->barrier(); }
+  void abort() override { inner_->abort(); }
+  std::vector<std::string> exchange(const std::string& mine) override { return inner_->exchange(mine); }
+
+  std::vector<std::tuple<std::string, int64_t, int>> log() {
+    std::lock_guard<std::mutex> lock(log_mu_);
+    static const char* names[] = {"?", "all_reduce", "all_gather", "reduce_scatter", "broadcast"};
+    std::vector<std::tuple<std::string, int64_t, int>> out;
+    for (auto& c : log_) out.emplace_back(names[c.kind], c.numel, c.queue);
+    return out;
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lock(log_mu_);
+    log_.clear();
+  }
+
+ private:
+  void note(Kind k, int64_t numel, Queue q, const at::Tensor& payload) {
+    count(k, payload);
+    std::lock_guard<std::mutex> lock(log_mu_);
+    log_.push_back({(int)k, numel, (int)q});
+  }
+  std::shared_ptr<Communicator> inner_;
+  std::mutex log_mu_;
+  std::vector<RecordedCall> log_;
+};
+
+std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg) {
+  return std::make_shared<C10dCommunicator>(std::move(pg));
+}
+
+std::shared_ptr<Communicator> make_recording_communicator(std::shared_ptr<Communicator> inner) {
+  return std::make_shared<RecordingCommunicator>(std::move(inner));
+}
+
+std::vector<std::tuple<std::string, int64_t, int>> recording_log(const std::shared_ptr<Communicator>& c, bool clear) {
+  auto* r = dynamic_cast<RecordingCommunicator*>(c.get());
+  TORCH_CHECK(r != nullptr, "not a recording communicator");
+  auto out = r->log();
+  if (clear) r->clear();
+  return out;
+}
+
+}  // namespace comm
+}  // namespace pda

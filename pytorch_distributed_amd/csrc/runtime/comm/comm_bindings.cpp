@@ -1,0 +1,122 @@
+// Python surface of the communication layer (`_C.Communicator`, `_C.CommWork`, factories).
+#include "communicator.h"
+#include "store.h"
+
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+#include <torch/extension.h>
+
+namespace py = pybind11;
+
+namespace pda {
+namespace comm {
+std::shared_ptr<Communicator> make_rccl_communicator(std::shared_ptr<Rendezvous> rv, int device, double timeout_s);
+std::shared_ptr<Communicator> make_socket_communicator(std::shared_ptr<Rendezvous> rv, double timeout_s);
+std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg);
+std::shared_ptr<Communicator> make_recording_communicator(std::shared_ptr<Communicator> inner);
+std::vector<std::tuple<std::string, int64_t, int>> recording_log(const std::shared_ptr<Communicator>& c, bool clear);
+int64_t rccl_stream_handle(const std::shared_ptr<Communicator>& c, int q);
+int rccl_version(const std::shared_ptr<Communicator>& c);
+}  // namespace comm
+}  // namespace pda
+
+namespace {
+
+using namespace pda::comm;
+
+RedOp parse_op(const std::string& s) {
+  if (s == "sum") return RedOp::kSum;
+  if (s == "avg" || s == "mean") return RedOp::kAvg;
+  if (s == "max") return RedOp::kMax;
+  TORCH_CHECK(false, "unknown reduction '", s, "' (sum, avg, max)");
+}
+
+Queue parse_queue(int q) {
+  TORCH_CHECK(q == 0 || q == 1, "queue must be 0 (gather) or 1 (reduce)");
+  return q == 0 ? Queue::kGather : Queue::kReduce;
+}
+
+}  // namespace
+
+void bind_comm(py::module_& m) {
+  py::class_<Work, std::shared_ptr<Work>>(m, "CommWork")
+      .def("wait", &Work::wait, py::call_guard<py::gil_scoped_release>())
+      .def("synchronize", &Work::synchronize, py::call_guard<py::gil_scoped_release>())
+      .def("completed", &Work::completed);
+
+  py::class_<Communicator, std::shared_ptr<Communicator>>(m, "Communicator")
+      .def_property_readonly("rank", &Communicator::rank)
+      .def_property_readonly("world_size", &Communicator::world)
+      .def_property_readonly("backend", &Communicator::backend)
+      .def_property_readonly("on_gpu", &Communicator::on_gpu)
+      .def_property_readonly("aborted", &Communicator::aborted)
+      .def(
+          "all_reduce",
+          [](Communicator& c, const at::Tensor& t, const std::string& op, int queue) {
+            return c.all_reduce(t, parse_op(op), parse_queue(queue));
+          },
+          py::arg("tensor"), py::arg("op") = "sum", py::arg("queue") = 1, py::call_guard<py::gil_scoped_release>())
+      .def(
+          "all_gather",
+          [](Communicator& c, const at::Tensor& out, const at::Tensor& in, int queue) {
+            return c.all_gather(out, in, parse_queue(queue));
+          },
+          py::arg("out"), py::arg("input"), py::arg("queue") = 0, py::call_guard<py::gil_scoped_release>())
+      .def(
+          "reduce_scatter",
+          [](Communicator& c, const at::Tensor& out, const at::Tensor& in, const std::string& op, int queue) {
+            return c.reduce_scatter(out, in, parse_op(op), parse_queue(queue));
+          },
+          py::arg("out"), py::arg("input"), py::arg("op") = "sum", py::arg("queue") = 1,
+          py::call_guard<py::gil_scoped_release>())
+      .def(
+          "broadcast",
+          [](Communicator& c, const at::Tensor& t, int root, int queue) { return c.broadcast(t, root, parse_queue(queue)); },
+          py::arg("tensor"), py::arg("root") = 0, py::arg("queue") = 0, py::call_guard<py::gil_scoped_release>())
+      .def("barrier", &Communicator::barrier, py::call_guard<py::gil_scoped_release>())
+      .def("abort", &Communicator::abort, py::call_guard<py::gil_scoped_release>())
+      .def(
+          "exchange",
+          [](Communicator& c, const py::bytes& mine) {
+            std::vector<std::string> got;
+            const std::string s = mine;
+            {
+              py::gil_scoped_release nogil;
+              got = c.exchange(s);
+            }
+            py::list out;
+            for (auto& g : got) out.append(py::bytes(g));
+            return out;
+          },
+          py::arg("mine"))
+      .def("counters",
+           [](Communicator& c) {
+             const Counters& k = c.counters();
+             py::dict d;
+             d["all_reduce"] = k.all_reduce;
+             d["all_gather"] = k.all_gather;
+             d["reduce_scatter"] = k.reduce_scatter;
+             d["broadcast"] = k.broadcast;
+             d["bytes"] = k.bytes;
+             return d;
+           })
+      .def("stream_handle", [](std::shared_ptr<Communicator> c, int q) { return rccl_stream_handle(c, q); },
+           py::arg("queue"), "hipStream_t of an RCCL communicator's queue as an integer (for traces)")
+      .def("rccl_version", [](std::shared_ptr<Communicator> c) { return rccl_version(c); })
+      .def("log", [](std::shared_ptr<Communicator> c, bool clear) { return recording_log(c, clear); },
+           py::arg("clear") = false, "(kind, elements, queue) per collective of a recording communicator");
+
+  m.def(
+      "create_communicator",
+      [](const std::string& kind, int rank, int world, const std::string& host, int port, int device, double timeout_s,
+         const std::string& job_id) -> std::shared_ptr<Communicator> {
+        TORCH_CHECK(world >= 1 && rank >= 0 && rank < world, "create_communicator: bad rank / world ", rank, " / ", world);
+        auto rv = rendezvous_from_env(rank, world, host, port, timeout_s, job_id);
+        if (kind == "rccl") return make_rccl_communicator(std::move(rv), device, timeout_s);
+        if (kind == "socket") return make_socket_communicator(std::move(rv), timeout_s);
+        TORCH_CHECK(false, "create_communicator: unknown kind '", kind, "' (rccl, socket)");
+      },
+      py::arg("kind"), py::arg("rank"), py::arg("world_size"), py::arg("host"), py::arg("port"), py::arg("device") = 0,
+      py::arg("timeout_s") = 600.0, py::arg("job_id") = "", py::call_guard<py::gil_scoped_release>());
+  m.def("wrap_process_group", &make_c10d_communicator, py::arg("process_group"));
+  m.def("recording_communicator", &make_recording_communicator, py::arg("inner"));
+}

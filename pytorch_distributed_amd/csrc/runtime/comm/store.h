@@ -1,0 +1,96 @@
+// Rendezvous key-value store of the framework's own communication layer.
+//
+// One rank (rank 0) hosts a StoreServer thread; every rank, rank 0 included, talks to it
+// through a StoreClient over TCP. It carries what a communicator needs before it exists:
+// the RCCL unique id, the listening addresses of the CPU socket mesh, barriers and small
+// agreement checks. Blocking `get` (the server parks the request until the key is set) and
+// an atomic `add` are the only primitives beyond `set`.
+//
+// Address: MASTER_ADDR, port MASTER_PORT + 1 by default (MASTER_PORT itself belongs to the
+// launcher's own store). When that port is taken, rank 0 walks upwards and the clients
+// find the right server through the handshake, which carries a job identifier.
+//
+// Role in the reference: the TCPStore rendezvous hidden inside
+// dist.init_process_group(backend='nccl') (assignments/assignment1/train_ddp.py:23-24).
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace pda {
+namespace comm {
+
+// Small socket helpers shared by the store and the CPU socket communicator.
+namespace net {
+int listen_on(const std::string& host, int port, int backlog);  // returns fd or -1 (port in use)
+int bound_port(int fd);
+int connect_to(const std::string& host, int port, double timeout_s);  // retries until the deadline; -1 on failure
+void send_all(int fd, const void* data, size_t n);
+void recv_all(int fd, void* data, size_t n, double timeout_s);  // throws on timeout / peer close
+void set_nodelay(int fd);
+std::string local_address(int fd);  // the local IP of a connected socket
+}  // namespace net
+
+class StoreServer {
+ public:
+  // Binds `base_port`, or the first free port of the next `scan` ones.
+  StoreServer(const std::string& host, int base_port, int scan, std::string job_id);
+  ~StoreServer();
+  int port() const { return port_; }
+
+ private:
+  struct Client {
+    int fd = -1;
+    bool greeted = false;
+    std::vector<uint8_t> in;
+  };
+  void loop();
+  bool consume(Client& c);  // parses as many complete requests as `c.in` holds; false = drop client
+  void answer_waiters(const std::string& key);
+
+  std::string job_id_;
+  int listen_fd_ = -1, wake_fd_[2] = {-1, -1}, port_ = 0;
+  std::thread thread_;
+  std::atomic<bool> stop_{false};
+  std::map<std::string, std::string> data_;
+  std::map<std::string, std::vector<int>> waiters_;
+  std::map<int, Client> clients_;
+};
+
+class StoreClient {
+ public:
+  // Tries base_port .. base_port+scan-1 until a server answers the handshake for `job_id`.
+  StoreClient(const std::string& host, int base_port, int scan, const std::string& job_id, double timeout_s);
+  ~StoreClient();
+  void set(const std::string& key, const std::string& value);
+  std::string get(const std::string& key);  // blocks until the key exists (or the timeout passes)
+  int64_t add(const std::string& key, int64_t delta);
+  std::string local_address() const;
+  double timeout_s() const { return timeout_s_; }
+
+ private:
+  int fd_ = -1;
+  double timeout_s_;
+  std::mutex mu_;
+};
+
+// Both ends of the rendezvous for one process.
+struct Rendezvous {
+  std::unique_ptr<StoreServer> server;  // rank 0 only
+  std::unique_ptr<StoreClient> client;  // nullptr when world == 1
+  int rank = 0, world = 1;
+  int64_t barrier_seq = 0;
+  void barrier(const std::string& tag);
+};
+
+std::shared_ptr<Rendezvous> rendezvous_from_env(int rank, int world, const std::string& host, int port, double timeout_s,
+                                                const std::string& job_id);
+
+}  // namespace comm
+}  // namespace pda

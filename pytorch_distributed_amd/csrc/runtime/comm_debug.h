@@ -12,10 +12,12 @@
 #pragma once
 
 #include <ATen/ATen.h>
-#include <hip/hip_runtime_api.h>
-#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+#include <c10/util/Exception.h>
+
+#include "comm/communicator.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -37,34 +39,27 @@ inline bool serialize_enabled() {
   return on;
 }
 
-enum Kind : int64_t { kAllReduce = 1, kAllGather = 2, kReduceScatter = 3 };
-
-// Cross-rank agreement check; `like` supplies the device the communicator works on.
-inline void before(const c10::intrusive_ptr<c10d::ProcessGroup>& pg, Kind kind, int64_t numel, int64_t& sequence,
-                   const at::Tensor& like, const char* who) {
+// Cross-rank agreement check (host side, through the communicator's exchange primitive).
+inline void before(const std::shared_ptr<comm::Communicator>& c, comm::Kind kind, int64_t numel, const char* who) {
   static int64_t process_sequence = 0;  // one numbering for every collective of the process
-  sequence = ++process_sequence;
-  if (!check_enabled() || !pg || pg->getSize() <= 1) return;
-  at::Tensor mine = at::tensor({sequence, (int64_t)kind, numel}, at::TensorOptions().dtype(at::kLong)).to(like.device());
-  std::vector<at::Tensor> outs;
-  for (int r = 0; r < pg->getSize(); ++r) outs.push_back(at::empty_like(mine));
-  std::vector<std::vector<at::Tensor>> out_lists{outs};
-  std::vector<at::Tensor> ins{mine};
-  pg->allgather(out_lists, ins)->wait();
-  const at::Tensor mine_cpu = mine.cpu();
-  for (int r = 0; r < pg->getSize(); ++r) {
-    const at::Tensor other = out_lists[0][r].cpu();
-    TORCH_CHECK(at::equal(other, mine_cpu), who, ": collective mismatch between rank ", pg->getRank(), " and rank ", r,
+  const int64_t sequence = ++process_sequence;
+  if (!check_enabled() || !c || c->world() <= 1) return;
+  int64_t mine[3] = {sequence, (int64_t)kind, numel};
+  const std::string bytes(reinterpret_cast<const char*>(mine), sizeof(mine));
+  const std::vector<std::string> all = c->exchange(bytes);
+  for (int r = 0; r < (int)all.size(); ++r) {
+    int64_t other[3] = {0, 0, 0};
+    if (all[r].size() == sizeof(other)) std::memcpy(other, all[r].data(), sizeof(other));
+    TORCH_CHECK(all[r] == bytes, who, ": collective mismatch between rank ", c->rank(), " and rank ", r,
                 " — this rank is about to issue (sequence ", sequence, ", kind ", (int64_t)kind, ", elements ", numel,
-                "), the other (sequence ", other[0].item<int64_t>(), ", kind ", other[1].item<int64_t>(), ", elements ",
-                other[2].item<int64_t>(), ")");
+                "), the other (sequence ", other[0], ", kind ", other[1], ", elements ", other[2], ")");
   }
 }
 
-inline void after(const c10::intrusive_ptr<c10d::Work>& work, const at::Tensor& like) {
+inline void after(const std::shared_ptr<comm::Work>& work) {
   if (!serialize_enabled() || !work) return;
   work->wait();
-  if (like.is_cuda()) (void)hipDeviceSynchronize();
+  work->synchronize();
 }
 
 }  // namespace comm_debug

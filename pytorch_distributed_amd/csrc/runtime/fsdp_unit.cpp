@@ -14,21 +14,31 @@
 //     reduce-scattered (FULL_SHARD / SHARD_GRAD_OP) or all-reduced (NO_SHARD) asynchronously
 //     and, under FULL_SHARD, the parameters are resharded at once.
 //
-// ShardedRuntime — the units of one model in execution order, the sync / no_sync switch,
-// and the single end-of-backward callback that waits for all outstanding reductions and
-// publishes the reduced shard as `.grad` of each unit's flat shard parameter.
+// ShardedRuntime — the units of one model in execution order and the whole schedule:
+//   * pre_forward(i): all-gather unit i (if it is not already in flight), start the
+//     all-gathers of the next `forward_prefetch` units on the gather queue, then make the
+//     compute stream wait for unit i only;
+//   * post_forward(i, outputs): reshard (FULL_SHARD) and plant C++ gradient hooks on the
+//     unit's outputs: the first gradient that reaches them in backward is the unit's
+//     "pre-backward" moment — unit i is all-gathered again and the units backward will
+//     visit next are prefetched. No Python runs in backward;
+//   * one end-of-backward callback waits for all outstanding reductions and publishes the
+//     reduced shard as `.grad` of each unit's flat shard parameter.
+//
+// All-gathers run on the communicator's gather queue, reductions on its reduce queue, so a
+// prefetch never waits behind a gradient reduction.
 //
 // Safety rule for every buffer: storage is only released after the collective that reads
 // or writes it has been waited on from the stream that will reuse the memory.
 //
-// Collectives go through c10d::ProcessGroup (RCCL on GPUs, gloo on CPUs). Replaces the
-// torch FSDP wrapping at assignments/assignment1/train_fsdp.py:64-81.
+// Replaces the torch FSDP wrapping at assignments/assignment1/train_fsdp.py:64-81.
 #include <c10/core/StorageImpl.h>
 #include <torch/csrc/autograd/engine.h>
+#include <torch/csrc/autograd/graph_task.h>
 #include <torch/csrc/autograd/utils/lambda_post_hook.h>
-#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
+#include "comm/communicator.h"
 #include "comm_debug.h"
 
 #include <memory>
@@ -38,6 +48,12 @@
 namespace py = pybind11;
 
 namespace {
+
+using pda::comm::Communicator;
+using pda::comm::Kind;
+using pda::comm::Queue;
+using pda::comm::RedOp;
+using pda::comm::Work;
 
 constexpr int64_t kAlignElems = 64;
 enum Strategy : int { kFullShard = 0, kShardGradOp = 1, kNoShard = 2 };
@@ -55,8 +71,6 @@ void release_storage(const at::Tensor& t) {
   t.storage().unsafeGetStorageImpl()->reset();
 }
 
-bool storage_allocated(const at::Tensor& t) { return t.storage().nbytes() > 0; }
-
 void allocate_storage(const at::Tensor& t, int64_t numel) {
   auto* impl = t.storage().unsafeGetStorageImpl();
   if (impl->nbytes() > 0) return;
@@ -70,16 +84,19 @@ class ShardedRuntime;
 
 class ShardedUnit {
  public:
-  ShardedUnit(std::vector<at::Tensor> params, c10::intrusive_ptr<c10d::ProcessGroup> pg, int strategy,
+  ShardedUnit(std::vector<at::Tensor> params, std::shared_ptr<Communicator> comm, int strategy,
               bool force_collectives, bool reduce_fp32)
-      : params_(std::move(params)), pg_(std::move(pg)), strategy_(strategy),
+      : params_(std::move(params)), comm_(std::move(comm)), strategy_(strategy),
         force_collectives_(force_collectives), reduce_fp32_(reduce_fp32) {
     TORCH_CHECK(!params_.empty(), "ShardedUnit: no parameters");
     TORCH_CHECK(strategy_ >= 0 && strategy_ <= 2, "ShardedUnit: bad strategy");
-    world_ = pg_ ? pg_->getSize() : 1;
-    rank_ = pg_ ? pg_->getRank() : 0;
-    native_avg_ = pg_ && pg_->getBackendName() == "nccl";
+    world_ = comm_ ? comm_->world() : 1;
+    rank_ = comm_ ? comm_->rank() : 0;
     const at::Tensor& p0 = params_[0];
+    if (comm_) {
+      TORCH_CHECK(comm_->on_gpu() == p0.is_cuda(), "ShardedUnit: the '", comm_->backend(),
+                  "' communicator does not work on ", p0.is_cuda() ? "GPU" : "CPU", " tensors");
+    }
     int64_t off = 0;
     for (auto& p : params_) {
       TORCH_CHECK(p.is_leaf() && p.requires_grad(), "ShardedUnit: parameters must be trainable leaves");
@@ -112,14 +129,17 @@ class ShardedUnit {
         shard_master_ = full_param_;
       }
     } else {
-      shard_master_ = shard.to(at::kFloat);  // .to() copies even when already fp32? no: clone below
-      if (!mixed_) shard_master_ = shard.clone();
+      shard_master_ = mixed_ ? shard.to(at::kFloat) : shard.clone();
       if (mixed_) shard_lowp_ = shard.clone();
     }
     unsharded_ = true;
     if (strategy_ != kNoShard) reshard();
     full_grad_ = make_resizable(padded_numel_, opts);
     release_storage(full_grad_);
+    if (reduce_fp32_ && mixed_) {
+      wide_grad_ = make_resizable(padded_numel_, opts.dtype(at::kFloat));
+      release_storage(wide_grad_);
+    }
     grad_written_.assign(params_.size(), false);
     sunk_.assign(params_.size(), false);
     counted_.assign(params_.size(), false);
@@ -135,21 +155,21 @@ class ShardedUnit {
     hook_keys_.clear();
   }
 
+  bool communicates() const { return comm_ && (world_ > 1 || force_collectives_); }
+
   // ---- parameters ---------------------------------------------------------------
   // Starts (or joins) the all-gather of this unit's parameters; returns at once.
   void unshard() {
     if (strategy_ == kNoShard || unsharded_ || ag_work_ || ag_issued_) return;
     allocate_storage(full_param_, padded_numel_);
     const at::Tensor& src = mixed_ ? shard_lowp_ : shard_master_;
-    if (world_ == 1 && !force_collectives_) {
+    if (!communicates()) {
       at::NoGradGuard ng;
       full_param_.copy_(src);
     } else {
-      at::Tensor out = full_param_;
-      at::Tensor in = src;
-      pda::comm_debug::before(pg_, pda::comm_debug::kAllGather, out.numel(), debug_sequence_, out, "ShardedUnit");
-      ag_work_ = pg_->_allgather_base(out, in);
-      pda::comm_debug::after(ag_work_, out);
+      pda::comm_debug::before(comm_, Kind::kAllGather, full_param_.numel(), "ShardedUnit");
+      ag_work_ = comm_->all_gather(full_param_, src, Queue::kGather);
+      pda::comm_debug::after(ag_work_);
       ++num_allgathers_;
     }
     ag_issued_ = true;
@@ -192,6 +212,37 @@ class ShardedUnit {
     if (mixed_) shard_lowp_.copy_(shard);
   }
 
+  // All ranks' shards of a shard-shaped tensor (fp32 master weights, optimizer moments),
+  // concatenated into a fresh flat tensor of padded_numel elements. Collective unless the
+  // unit is replicated. This is what makes full checkpoints fp32-faithful: the master
+  // weights are gathered themselves instead of being re-derived from the bf16 parameters.
+  at::Tensor gather_shards(const at::Tensor& shard) {
+    TORCH_CHECK(shard.numel() == shard_numel_, "gather_shards: expected ", shard_numel_, " elements, got ", shard.numel());
+    at::NoGradGuard ng;
+    at::Tensor flat = shard.detach().reshape({-1}).contiguous();
+    if (padded_numel_ == shard_numel_ || world_ == 1 || !comm_) return flat.clone();
+    at::Tensor full = at::empty({padded_numel_}, flat.options());
+    auto w = comm_->all_gather(full, flat, Queue::kGather);
+    w->wait();
+    return full;
+  }
+
+  // Inverse for loading: overwrites the fp32 master shard (and the low-precision mirror) with
+  // this rank's slice of a full flat tensor laid out like the unit.
+  void load_master_from_full(const at::Tensor& full) {
+    TORCH_CHECK(full.numel() == padded_numel_ || full.numel() == total_numel_, "load_master_from_full: size mismatch");
+    at::NoGradGuard ng;
+    at::Tensor padded = full.reshape({-1});
+    if (padded.numel() != padded_numel_) {
+      at::Tensor tmp = at::zeros({padded_numel_}, padded.options());
+      tmp.narrow(0, 0, padded.numel()).copy_(padded);
+      padded = tmp;
+    }
+    at::Tensor mine = strategy_ == kNoShard ? padded : padded.narrow(0, shard_index_ * shard_numel_, shard_numel_);
+    shard_master_.copy_(mine);
+    if (mixed_) shard_lowp_.copy_(strategy_ == kNoShard ? padded : mine);
+  }
+
   // ---- accessors for the Python wrapper -------------------------------------------
   at::Tensor shard_master() const { return shard_master_; }
   at::Tensor shard_lowp() const { return shard_lowp_; }
@@ -204,6 +255,7 @@ class ShardedUnit {
   int64_t total_numel() const { return total_numel_; }
   int64_t shard_index() const { return shard_index_; }
   int strategy() const { return strategy_; }
+  bool mixed() const { return mixed_; }
   int64_t num_allgathers() const { return num_allgathers_; }
   int64_t num_reductions() const { return num_reductions_; }
   bool reshard_after_forward = true;  // FULL_SHARD non-root units; the wrapper clears it for the root
@@ -272,33 +324,29 @@ class ShardedUnit {
     // fp32 reduction of low-precision gradients: the collective runs on a widened copy (twice
     // the bytes on the wire, no rounding between the ranks' contributions); with an fp32 master
     // shard the reduced fp32 result is then the optimizer's gradient as it is.
-    const bool communicates = world_ > 1 || force_collectives_;
+    const bool comms = communicates();
     at::Tensor in = full_grad_;
-    if (reduce_fp32_ && communicates && full_grad_.scalar_type() != at::kFloat) {
+    if (wide_grad_.defined() && comms) {
       at::NoGradGuard ng;
-      in = full_grad_.to(at::kFloat);
-      reduce_input_ = in;  // kept alive until the collective has been waited for
+      allocate_storage(wide_grad_, padded_numel_);
+      wide_grad_.copy_(full_grad_);
+      in = wide_grad_;
     }
     if (strategy_ == kNoShard) {
       reduced_ = in;
-      if (communicates) {
-        std::vector<at::Tensor> ts{in};
-        c10d::AllreduceOptions opts;
-        opts.reduceOp = native_avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-        pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, in.numel(), debug_sequence_, in, "ShardedUnit");
-        rs_work_ = pg_->allreduce(ts, opts);
-        pda::comm_debug::after(rs_work_, in);
+      if (comms) {
+        pda::comm_debug::before(comm_, Kind::kAllReduce, in.numel(), "ShardedUnit");
+        rs_work_ = comm_->all_reduce(in, RedOp::kAvg, Queue::kReduce);
+        pda::comm_debug::after(rs_work_);
         ++num_reductions_;
       }
-    } else if (!communicates) {
+    } else if (!comms) {
       reduced_ = full_grad_.narrow(0, 0, shard_numel_);
     } else {
       reduced_ = at::empty({shard_numel_}, in.options());
-      c10d::ReduceScatterOptions opts;
-      opts.reduceOp = native_avg_ ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-      pda::comm_debug::before(pg_, pda::comm_debug::kReduceScatter, in.numel(), debug_sequence_, in, "ShardedUnit");
-      rs_work_ = pg_->_reduce_scatter_base(reduced_, in, opts);
-      pda::comm_debug::after(rs_work_, in);
+      pda::comm_debug::before(comm_, Kind::kReduceScatter, in.numel(), "ShardedUnit");
+      rs_work_ = comm_->reduce_scatter(reduced_, in, RedOp::kAvg, Queue::kReduce);
+      pda::comm_debug::after(rs_work_);
       ++num_reductions_;
     }
   }
@@ -311,10 +359,10 @@ class ShardedUnit {
       rs_work_.reset();
     }
     at::NoGradGuard ng;
-    if (!native_avg_ && world_ > 1) reduced_.div_((double)world_);
     TORCH_CHECK(flat_param_.defined(), "ShardedUnit: flat parameter was never registered");
     at::Tensor& g = flat_param_.mutable_grad();
-    const bool aliases_buffer = reduced_.storage().is_alias_of(full_grad_.storage());
+    const bool aliases_buffer = reduced_.storage().is_alias_of(full_grad_.storage()) ||
+                                (wide_grad_.defined() && reduced_.storage().is_alias_of(wide_grad_.storage()));
     if (!g.defined()) {
       if (reduced_.scalar_type() == flat_param_.scalar_type() && !aliases_buffer) {
         g = reduced_;
@@ -325,27 +373,42 @@ class ShardedUnit {
       g.add_(reduced_);
     }
     reduced_.reset();
-    reduce_input_.reset();
+    if (wide_grad_.defined()) release_storage(wide_grad_);
     release_storage(full_grad_);
     grad_allocated_ = false;
     std::fill(grad_written_.begin(), grad_written_.end(), false);
   }
 
+  // Forget an interrupted pass (a backward that raised): nothing may stay in flight.
+  void abandon_pass() {
+    if (rs_work_) {
+      rs_work_->wait();
+      rs_work_.reset();
+    }
+    reduced_.reset();
+    if (wide_grad_.defined()) release_storage(wide_grad_);
+    if (grad_allocated_) {
+      release_storage(full_grad_);
+      grad_allocated_ = false;
+    }
+    std::fill(grad_written_.begin(), grad_written_.end(), false);
+    std::fill(sunk_.begin(), sunk_.end(), false);
+    reset_pass();
+  }
+
   std::vector<at::Tensor> params_;
-  c10::intrusive_ptr<c10d::ProcessGroup> pg_;
+  std::shared_ptr<Communicator> comm_;
   int strategy_;
   bool force_collectives_;
   bool reduce_fp32_ = false;  // reduce low-precision gradients through an fp32 copy
-  at::Tensor reduce_input_;
   int world_ = 1, rank_ = 0;
-  bool native_avg_ = false;
   bool mixed_ = false;
   std::vector<int64_t> offsets_;
   int64_t total_numel_ = 0, shard_numel_ = 0, padded_numel_ = 0, shard_index_ = 0;
 
-  at::Tensor shard_master_, shard_lowp_, full_param_, full_grad_, flat_param_, reduced_;
+  at::Tensor shard_master_, shard_lowp_, full_param_, full_grad_, wide_grad_, flat_param_, reduced_;
   bool unsharded_ = false, ag_issued_ = false;
-  c10::intrusive_ptr<c10d::Work> ag_work_, rs_work_;
+  std::shared_ptr<Work> ag_work_, rs_work_;
   bool grad_allocated_ = false, reduce_launched_ = false, unit_done_ = false;
   std::vector<bool> grad_written_, counted_, sunk_;
   size_t pending_ = 0;
@@ -353,35 +416,102 @@ class ShardedUnit {
 
   std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
   std::vector<uintptr_t> hook_keys_;
-  int64_t num_allgathers_ = 0, num_reductions_ = 0, debug_sequence_ = 0;
+  int64_t num_allgathers_ = 0, num_reductions_ = 0;
 };
 
 class ShardedRuntime {
  public:
-  explicit ShardedRuntime(std::vector<std::shared_ptr<ShardedUnit>> units) : units_(std::move(units)) {
+  ShardedRuntime(std::vector<std::shared_ptr<ShardedUnit>> units, int forward_prefetch, int backward_prefetch)
+      : units_(std::move(units)), forward_prefetch_(forward_prefetch), backward_prefetch_(backward_prefetch),
+        alive_(std::make_shared<bool>(true)) {
     for (auto& u : units_) {
       TORCH_CHECK(u->runtime_ == nullptr, "ShardedRuntime: a unit already belongs to a runtime");
       u->runtime_ = this;
     }
   }
   ~ShardedRuntime() {
+    *alive_ = false;
     for (auto& u : units_) u->runtime_ = nullptr;
   }
 
   void set_sync(bool s) { require_sync_ = s; }
   bool sync_enabled() const { return require_sync_; }
   bool in_backward() const { return in_pass_ || pre_backward_seen_; }
-  void mark_pre_backward() { pre_backward_seen_ = true; }
+
+  // ---- schedule -------------------------------------------------------------------
+  void pre_forward(int64_t index) {
+    TORCH_CHECK(index >= 0 && index < (int64_t)units_.size(), "ShardedRuntime: bad unit index");
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    if (index == 0 && in_backward() && torch::autograd::get_current_graph_task_id() == -1) {
+      // A new top-level forward (no autograd graph task is executing on this thread, so this is
+      // not a recomputation) while a pass is still marked open: the previous backward raised
+      // before its end-of-backward callback could run. Close it.
+      for (auto& u : units_) u->abandon_pass();
+      in_pass_ = false;
+      pre_backward_seen_ = false;
+      ++num_abandoned_passes_;
+    }
+    ShardedUnit& u = *units_[index];
+    u.unshard();
+    if (!in_backward()) {
+      for (int k = 1; k <= forward_prefetch_; ++k)  // next units' all-gathers overlap this unit's math
+        if (index + k < (int64_t)units_.size()) units_[index + k]->unshard();
+    }
+    u.wait_unshard();
+  }
+
+  void post_forward(int64_t index, const std::vector<at::Tensor>& outputs) {
+    TORCH_CHECK(index >= 0 && index < (int64_t)units_.size(), "ShardedRuntime: bad unit index");
+    if (torch::autograd::GradMode::is_enabled()) {
+      // The first gradient reaching any output of the unit marks the start of its backward.
+      auto fired = std::make_shared<bool>(false);
+      auto alive = alive_;
+      for (const at::Tensor& o : outputs) {
+        if (!o.defined() || !o.requires_grad()) continue;
+        o.register_hook([this, index, fired, alive](const at::Tensor& grad) -> at::Tensor {
+          if (*alive && !*fired) {
+            *fired = true;
+            this->pre_backward(index);
+          }
+          return grad;
+        });
+      }
+    }
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    ShardedUnit& u = *units_[index];
+    // A recomputed forward inside backward must not reshard: the backward still needs the parameters.
+    if (u.strategy_ == kFullShard && u.reshard_after_forward && !in_backward()) u.reshard();
+  }
+
+  void pre_backward(int64_t index) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    pre_backward_seen_ = true;
+    ShardedUnit& u = *units_[index];
+    u.unshard();
+    // Backward visits the units as root (LM head), last block, ..., first block, root
+    // (embeddings); the root never reshards in between, so the chain to prefetch is
+    // root -> n-1 -> n-2 -> ... -> 1.
+    int64_t j = index;
+    const int64_t n = (int64_t)units_.size();
+    for (int k = 0; k < backward_prefetch_; ++k) {
+      j = j == 0 ? n - 1 : j - 1;
+      if (j < 1) break;
+      units_[j]->unshard();
+    }
+    u.wait_unshard();
+  }
 
   // Called (under the mutex) by the first gradient hook of a backward pass.
   void begin_pass() {
     in_pass_ = true;
     for (auto& u : units_) u->reset_pass();
-    torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finish_pass(); });
+    torch::autograd::Engine::get_default_engine().queue_callback([this, alive = alive_] {
+      if (*alive) this->finish_pass();
+    });
   }
 
   void finish_pass() {
-    std::lock_guard<std::mutex> lock(mu_);
+    std::lock_guard<std::recursive_mutex> lock(mu_);
     if (!in_pass_) return;
     if (require_sync_) {
       // Units whose parameters did not all receive a gradient: reduce what there is, in
@@ -396,19 +526,24 @@ class ShardedRuntime {
     pre_backward_seen_ = false;
   }
 
-  std::mutex mu_;
+  int64_t num_abandoned_passes() const { return num_abandoned_passes_; }
+
+  std::recursive_mutex mu_;
   bool in_pass_ = false;
 
  private:
   std::vector<std::shared_ptr<ShardedUnit>> units_;
+  int forward_prefetch_ = 1, backward_prefetch_ = 1;
   bool require_sync_ = true;
   bool pre_backward_seen_ = false;
+  int64_t num_abandoned_passes_ = 0;
+  std::shared_ptr<bool> alive_;
 };
 
 std::pair<at::Tensor, bool> ShardedUnit::grad_slot(size_t i) {
   TORCH_CHECK(runtime_ != nullptr, "ShardedUnit: grad_slot before the unit joined a runtime");
   TORCH_CHECK(i < params_.size(), "ShardedUnit: bad parameter index");
-  std::lock_guard<std::mutex> lock(runtime_->mu_);
+  std::lock_guard<std::recursive_mutex> lock(runtime_->mu_);
   at::NoGradGuard ng;
   if (!grad_allocated_) {
     allocate_storage(full_grad_, padded_numel_);  // unwritten ranges are zeroed by launch_reduce
@@ -423,7 +558,7 @@ std::pair<at::Tensor, bool> ShardedUnit::grad_slot(size_t i) {
 
 void ShardedUnit::on_grad_ready(size_t i) {
   TORCH_CHECK(runtime_ != nullptr, "ShardedUnit: gradient arrived before the unit joined a runtime");
-  std::lock_guard<std::mutex> lock(runtime_->mu_);
+  std::lock_guard<std::recursive_mutex> lock(runtime_->mu_);
   if (!runtime_->in_pass_) runtime_->begin_pass();
   at::Tensor& g = params_[i].mutable_grad();
   if (sunk_[i]) {
@@ -459,15 +594,17 @@ void ShardedUnit::on_grad_ready(size_t i) {
 
 void bind_fsdp(py::module_& m) {
   py::class_<ShardedUnit, std::shared_ptr<ShardedUnit>>(m, "ShardedUnit")
-      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int, bool, bool>(),
-           py::arg("params"), py::arg("process_group"), py::arg("strategy"),
-           py::arg("force_collectives") = false, py::arg("reduce_fp32") = false)
+      .def(py::init<std::vector<at::Tensor>, std::shared_ptr<Communicator>, int, bool, bool>(), py::arg("params"),
+           py::arg("communicator"), py::arg("strategy"), py::arg("force_collectives") = false,
+           py::arg("reduce_fp32") = false)
       .def("unshard", &ShardedUnit::unshard)
       .def("wait_unshard", &ShardedUnit::wait_unshard)
       .def("reshard", &ShardedUnit::reshard)
       .def("is_unsharded", &ShardedUnit::is_unsharded)
       .def("unshard_in_flight", &ShardedUnit::unshard_in_flight)
       .def("refresh_shard_from_full", &ShardedUnit::refresh_shard_from_full)
+      .def("gather_shards", &ShardedUnit::gather_shards, py::arg("shard"), py::call_guard<py::gil_scoped_release>())
+      .def("load_master_from_full", &ShardedUnit::load_master_from_full, py::arg("full"))
       .def("remove_hooks", &ShardedUnit::remove_hooks)
       .def("shard_master", &ShardedUnit::shard_master)
       .def("shard_lowp", &ShardedUnit::shard_lowp)
@@ -481,13 +618,18 @@ void bind_fsdp(py::module_& m) {
       .def_property_readonly("total_numel", &ShardedUnit::total_numel)
       .def_property_readonly("shard_index", &ShardedUnit::shard_index)
       .def_property_readonly("strategy", &ShardedUnit::strategy)
+      .def_property_readonly("mixed", &ShardedUnit::mixed)
       .def_property_readonly("num_allgathers", &ShardedUnit::num_allgathers)
       .def_property_readonly("num_reductions", &ShardedUnit::num_reductions)
       .def_readwrite("reshard_after_forward", &ShardedUnit::reshard_after_forward);
   py::class_<ShardedRuntime, std::shared_ptr<ShardedRuntime>>(m, "ShardedRuntime")
-      .def(py::init<std::vector<std::shared_ptr<ShardedUnit>>>(), py::arg("units"))
+      .def(py::init<std::vector<std::shared_ptr<ShardedUnit>>, int, int>(), py::arg("units"),
+           py::arg("forward_prefetch") = 1, py::arg("backward_prefetch") = 1)
       .def("set_sync", &ShardedRuntime::set_sync)
       .def("sync_enabled", &ShardedRuntime::sync_enabled)
       .def("in_backward", &ShardedRuntime::in_backward)
-      .def("mark_pre_backward", &ShardedRuntime::mark_pre_backward);
+      .def("pre_forward", &ShardedRuntime::pre_forward, py::arg("index"), py::call_guard<py::gil_scoped_release>())
+      .def("post_forward", &ShardedRuntime::post_forward, py::arg("index"), py::arg("outputs"))
+      .def("pre_backward", &ShardedRuntime::pre_backward, py::arg("index"), py::call_guard<py::gil_scoped_release>())
+      .def_property_readonly("num_abandoned_passes", &ShardedRuntime::num_abandoned_passes);
 }

@@ -15,6 +15,13 @@
 // in place on the caller's stream with the caller's operands (every epilogue used here is
 // idempotent, so re-running a candidate is harmless). Plans live for the life of the process.
 //
+// Data-parallel jobs: every rank would otherwise time on its own and ranks could settle on
+// different kernels for the same problem (a few percent apart, i.e. a permanent straggler).
+// export_choices() / import_choices() move one rank's table to the others: the heuristic's
+// candidate list is deterministic for a given library and device, so the index of the winner
+// is portable. parallel/plan_sync.py runs a planning pass before the model is wrapped and
+// installs rank 0's choices everywhere.
+//
 // All matrices are ROW-major with unit column stride and an arbitrary row stride; hipBLASLt
 // is column-major, so out[M,N] = A'[M,K] . B'[K,N] is issued as out^T = B'^T . A'^T.
 #include <ATen/ATen.h>
@@ -106,9 +113,44 @@ class Planner {
     if (it == plans_.end()) it = plans_.emplace(key, make_plan(handle, key)).first;
     Plan& plan = it->second;
     set_pointers(plan, epilogue, bias);
-    if (plan.candidates < 0) choose(handle, plan, a, b, out, ws, stream);
+    if (plan.candidates < 0) {
+      Key probe = key;
+      probe.device = 0;
+      auto pin = pinned_.find(probe);
+      choose(handle, plan, a, b, out, ws, stream, pin == pinned_.end() ? -1 : pin->second);
+    }
     launch(handle, plan, plan.algo, a, b, out, ws, stream);
     ++stats_.calls;
+  }
+
+  using Choice = std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, bool, bool, int, int>;
+
+  // (m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue, chosen candidate) of every tuned plan.
+  std::vector<Choice> export_choices() {
+    std::lock_guard<std::mutex> lock(mu_);
+    std::vector<Choice> out;
+    for (auto& kv : plans_) {
+      const Key& k = kv.first;
+      if (kv.second.candidates > 0)
+        out.emplace_back(k.m, k.n, k.k, k.lda, k.ldb, k.ldo, k.trans_a, k.trans_b, k.epilogue, kv.second.chosen);
+    }
+    return out;
+  }
+
+  // Pins the candidate index per problem; plans already made for those problems are re-chosen
+  // (without timing) the next time they run.
+  void import_choices(const std::vector<Choice>& rows) {
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto& r : rows) {
+      Key k{0, std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r), std::get<4>(r), std::get<5>(r),
+            std::get<6>(r), std::get<7>(r), std::get<8>(r)};
+      pinned_[k] = std::get<9>(r);
+      for (auto& kv : plans_) {
+        Key probe = kv.first;
+        probe.device = 0;
+        if (!(probe < k) && !(k < probe) && kv.second.chosen != std::get<9>(r)) kv.second.candidates = -1;
+      }
+    }
   }
 
   py::dict stats() {
@@ -133,6 +175,7 @@ class Planner {
   std::map<int, hipblasLtHandle_t> handles_;
   std::map<int, at::Tensor> workspaces_;
   std::map<Key, Plan> plans_;
+  std::map<Key, int> pinned_;  // device-independent key (device = 0) -> candidate index adopted from another rank
   Stats stats_;
 
   hipblasLtHandle_t handle_for(int device) {
@@ -201,7 +244,7 @@ class Planner {
   }
 
   void choose(hipblasLtHandle_t handle, Plan& p, const at::Tensor& a, const at::Tensor& b, at::Tensor& out, void* ws,
-              hipStream_t stream) {
+              hipStream_t stream, int pinned) {
     hipblasLtMatmulPreference_t pref;
     PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
     PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
@@ -217,6 +260,11 @@ class Planner {
     p.candidates = returned;
     p.chosen = 0;
     p.algo = found[0].algo;
+    if (pinned >= 0 && pinned < returned && found[pinned].state == HIPBLAS_STATUS_SUCCESS) {
+      p.chosen = pinned;  // another rank's measured winner: adopt it, do not time
+      p.algo = found[pinned].algo;
+      return;
+    }
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &capturing);
     if (!tuning || returned == 1 || capturing != hipStreamCaptureStatusNone) return;
@@ -328,6 +376,10 @@ void bind_gemm(py::module_& m) {
     p.timed_runs = timed_runs;
   }, py::arg("tuning") = true, py::arg("max_candidates") = 48, py::arg("timed_runs") = 4);
   m.def("gemm_planner_stats", []() { return Planner::get().stats(); });
+  m.def("gemm_planner_export", []() { return Planner::get().export_choices(); },
+        "(m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue, chosen) of every tuned plan");
+  m.def("gemm_planner_import", [](const std::vector<Planner::Choice>& rows) { Planner::get().import_choices(rows); },
+        py::arg("rows"), "adopt another rank's choices (see gemm_planner_export)");
 }
 
 }  // namespace pda

@@ -6,20 +6,25 @@
 //     .grad is a view into its bucket, so reduction needs no gather / scatter copies and
 //     the optimizer sees the reduced values in place.
 //   * Post-accumulate hooks on every parameter's AccumulateGrad node (C++, no GIL). When
-//     the last gradient of a bucket has been accumulated, the bucket is all-reduced
-//     asynchronously. Buckets launch strictly in index order on every rank.
+//     the last gradient of a bucket has been accumulated, the bucket is reduced
+//     asynchronously on the communicator's reduction queue. Buckets launch strictly in
+//     index order on every rank.
 //   * One end-of-backward callback that launches whatever is still pending (buckets
 //     whose parameters received no gradient this pass) and makes the compute stream wait
 //     for all outstanding collectives (an event wait, never a host synchronisation on
 //     the GPU backend).
 //   * no_sync: hooks keep accumulating into the bucket views, nothing is launched.
 //
-// Collectives go through c10d::ProcessGroup, i.e. RCCL on GPUs ("nccl" backend, which
-// runs each collective on its own HIP stream and fences it against the caller's stream
-// with events) and gloo on CPUs, so the same reducer is exercised by the CPU tests.
+// Collectives go through pda::comm::Communicator (RCCL on the communicator's own HIP streams
+// on GPUs, the TCP mesh on CPUs), so the same reducer is exercised by the CPU tests.
 //
-// Bucket size: a ring all-reduce over xGMI is bound by one of the 7 point-to-point links
-// per GPU and every bucket is cut into world-size chunks, so buckets default to 64 MiB
+// Reduction algorithm per bucket: one all-reduce (AVG), or — `decompose` — a reduce-scatter
+// followed by an all-gather in place on the same queue. Over point-to-point xGMI links a
+// ring all-reduce is bound by one link per GPU; the two-phase form lets the library move a
+// different 1/W chunk to each of the W-1 peers at once. Which one wins at a given bucket
+// size is measured at start-up (parallel/autotune.py) rather than assumed.
+//
+// Bucket size: every bucket is cut into world-size chunks, so buckets default to 64 MiB
 // (8 MiB chunks at 8 GPUs) rather than the 25 MiB of NVSwitch-era defaults; the first
 // bucket is small so communication starts early in backward.
 //
@@ -28,9 +33,9 @@
 // assignments/assignment1/train/distributed_trainer.py:115-127.
 #include <torch/csrc/autograd/engine.h>
 #include <torch/csrc/autograd/utils/lambda_post_hook.h>
-#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
+#include "comm/communicator.h"
 #include "comm_debug.h"
 
 #include <memory>
@@ -40,6 +45,12 @@
 namespace py = pybind11;
 
 namespace {
+
+using pda::comm::Communicator;
+using pda::comm::Kind;
+using pda::comm::Queue;
+using pda::comm::RedOp;
+using pda::comm::Work;
 
 constexpr int64_t kAlignElems = 64;  // every parameter starts on a 128-byte (bf16) / 256-byte (fp32) boundary
 
@@ -51,20 +62,25 @@ struct Bucket {
   std::vector<int64_t> offsets;  // element offset of each parameter inside `flat`
   size_t pending = 0;            // parameters whose gradient has not arrived this pass
   bool launched = false;
-  at::Tensor wide;               // fp32 copy that is reduced instead of `flat` (fp32-reduction option)
-  c10::intrusive_ptr<c10d::Work> work;
+  at::Tensor wide;               // persistent fp32 copy that is reduced instead of `flat` (fp32-reduction option)
+  bool wide_in_flight = false;
+  std::vector<std::shared_ptr<Work>> work;
 };
 
 class GradReducer {
  public:
-  GradReducer(std::vector<at::Tensor> params, c10::intrusive_ptr<c10d::ProcessGroup> pg,
-              int64_t bucket_cap_bytes, int64_t first_bucket_bytes, bool force_collectives, bool reduce_fp32)
-      : params_(std::move(params)), pg_(std::move(pg)), force_collectives_(force_collectives),
-        reduce_fp32_(reduce_fp32) {
+  GradReducer(std::vector<at::Tensor> params, std::shared_ptr<Communicator> comm, int64_t bucket_cap_bytes,
+              int64_t first_bucket_bytes, bool force_collectives, bool reduce_fp32, bool decompose)
+      : params_(std::move(params)), comm_(std::move(comm)), force_collectives_(force_collectives),
+        reduce_fp32_(reduce_fp32), decompose_(decompose) {
     TORCH_CHECK(!params_.empty(), "GradReducer: no parameters");
     TORCH_CHECK(bucket_cap_bytes > 0 && first_bucket_bytes > 0, "GradReducer: bucket sizes must be positive");
-    world_ = pg_ ? pg_->getSize() : 1;
-    backend_ = pg_ ? pg_->getBackendName() : "none";
+    world_ = comm_ ? comm_->world() : 1;
+    rank_ = comm_ ? comm_->rank() : 0;
+    if (comm_) {
+      TORCH_CHECK(comm_->on_gpu() == params_[0].is_cuda(), "GradReducer: the '", comm_->backend(),
+                  "' communicator does not work on ", params_[0].is_cuda() ? "GPU" : "CPU", " tensors");
+    }
     build_buckets(bucket_cap_bytes, first_bucket_bytes);
     install_hooks();
   }
@@ -87,6 +103,21 @@ class GradReducer {
     for (auto& b : buckets_) b.flat.zero_();
   }
 
+  // Called at the start of every wrapper forward. A backward that raised never ran its
+  // end-of-backward callback, which would leave the pass open and make the next backward skip
+  // its set-up (no bucket launched, optimizer stepping on unsynchronised gradients): close it.
+  void prepare_forward() {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (!in_pass_) return;
+    for (auto& b : buckets_) {
+      for (auto& w : b.work) w->wait();
+      b.work.clear();
+      b.wide_in_flight = false;
+    }
+    in_pass_ = false;
+    ++num_abandoned_passes_;
+  }
+
   std::vector<at::Tensor> bucket_tensors() const {
     std::vector<at::Tensor> out;
     for (auto& b : buckets_) out.push_back(b.flat);
@@ -102,6 +133,7 @@ class GradReducer {
   int64_t num_collectives() const { return num_collectives_; }
   int64_t num_buckets() const { return (int64_t)buckets_.size(); }
   int64_t num_rebound_grads() const { return num_rebound_; }
+  int64_t num_abandoned_passes() const { return num_abandoned_passes_; }
 
  private:
   // ---- construction -------------------------------------------------------------
@@ -117,7 +149,9 @@ class GradReducer {
       if (cur.empty()) return;
       const at::Tensor& p0 = params_[cur[0]];
       Bucket b;
-      b.flat = at::zeros({cur_elems}, p0.options().requires_grad(false));
+      // The two-phase reduction needs world equal chunks; pad the bucket (never a parameter).
+      const int64_t total = decompose_ ? align_up(cur_elems, kAlignElems * world_) : cur_elems;
+      b.flat = at::zeros({total}, p0.options().requires_grad(false));
       int64_t off = 0;
       for (size_t idx : cur) {
         b.params.push_back(idx);
@@ -186,7 +220,7 @@ class GradReducer {
     for (auto& b : buckets_) {
       b.pending = b.params.size();
       b.launched = false;
-      b.work.reset();
+      b.work.clear();
     }
     ready_.assign(params_.size(), false);
     torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finish_pass(); });
@@ -226,23 +260,32 @@ class GradReducer {
 
   void launch(Bucket& b) {
     b.launched = true;
-    if (world_ == 1 && !force_collectives_) return;
-    // fp32 reduction of low-precision gradients: the bucket is widened, the wide copy is
-    // reduced (twice the bytes on the wire, no rounding between the ranks' contributions) and
-    // narrowed back into the bucket when the pass finishes.
+    if (!comm_ || (world_ == 1 && !force_collectives_)) return;
+    // fp32 reduction of low-precision gradients: the bucket is widened into a persistent fp32
+    // twin, the twin is reduced (twice the bytes on the wire, no rounding between the ranks'
+    // contributions) and narrowed back into the bucket when the pass finishes.
     at::Tensor payload = b.flat;
     if (reduce_fp32_ && b.flat.scalar_type() != at::kFloat) {
       at::NoGradGuard ng;
-      b.wide = b.flat.to(at::kFloat);
+      if (!b.wide.defined()) b.wide = at::empty(b.flat.sizes(), b.flat.options().dtype(at::kFloat));
+      b.wide.copy_(b.flat);
+      b.wide_in_flight = true;
       payload = b.wide;
     }
-    std::vector<at::Tensor> tensors{payload};
-    c10d::AllreduceOptions opts;
-    const bool native_avg = backend_ == "nccl";
-    opts.reduceOp = native_avg ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-    pda::comm_debug::before(pg_, pda::comm_debug::kAllReduce, payload.numel(), debug_sequence_, payload, "GradReducer");
-    b.work = pg_->allreduce(tensors, opts);
-    pda::comm_debug::after(b.work, payload);
+    if (decompose_ && world_ > 1) {
+      const int64_t chunk = payload.numel() / world_;
+      at::Tensor mine = payload.narrow(0, rank_ * chunk, chunk);
+      pda::comm_debug::before(comm_, Kind::kReduceScatter, payload.numel(), "GradReducer");
+      b.work.push_back(comm_->reduce_scatter(mine, payload, RedOp::kAvg, Queue::kReduce));
+      pda::comm_debug::after(b.work.back());
+      pda::comm_debug::before(comm_, Kind::kAllGather, payload.numel(), "GradReducer");
+      b.work.push_back(comm_->all_gather(payload, mine, Queue::kReduce));  // same queue: ordered behind the scatter
+      pda::comm_debug::after(b.work.back());
+    } else {
+      pda::comm_debug::before(comm_, Kind::kAllReduce, payload.numel(), "GradReducer");
+      b.work.push_back(comm_->all_reduce(payload, RedOp::kAvg, Queue::kReduce));
+      pda::comm_debug::after(b.work.back());
+    }
     ++num_collectives_;
   }
 
@@ -250,28 +293,25 @@ class GradReducer {
     std::lock_guard<std::mutex> lock(mu_);
     if (!in_pass_) return;
     launch_ready_buckets(/*flush=*/true);
-    const bool native_avg = backend_ == "nccl";
     for (auto& b : buckets_) {
-      if (!b.work) continue;
-      b.work->wait();  // GPU: current stream waits on the collective's event; CPU: blocks
-      at::NoGradGuard ng;
-      at::Tensor& reduced = b.wide.defined() ? b.wide : b.flat;
-      if (!native_avg && world_ > 1) reduced.div_((double)world_);
-      if (b.wide.defined()) {
+      if (b.work.empty()) continue;
+      for (auto& w : b.work) w->wait();  // GPU: current stream waits on the collective's event; CPU: done already
+      if (b.wide_in_flight) {
+        at::NoGradGuard ng;
         b.flat.copy_(b.wide);
-        b.wide.reset();
+        b.wide_in_flight = false;
       }
-      b.work.reset();
+      b.work.clear();
     }
     in_pass_ = false;
   }
 
   std::vector<at::Tensor> params_;
-  c10::intrusive_ptr<c10d::ProcessGroup> pg_;
-  int world_ = 1;
-  std::string backend_;
+  std::shared_ptr<Communicator> comm_;
+  int world_ = 1, rank_ = 0;
   bool force_collectives_ = false;
   bool reduce_fp32_ = false;
+  bool decompose_ = false;
   bool require_sync_ = true;
   bool in_pass_ = false;
   size_t next_bucket_ = 0;
@@ -281,24 +321,27 @@ class GradReducer {
   std::vector<std::shared_ptr<torch::autograd::Node>> accumulators_;
   std::vector<uintptr_t> hook_keys_;
   std::mutex mu_;
-  int64_t num_collectives_ = 0, debug_sequence_ = 0;
+  int64_t num_collectives_ = 0;
   int64_t num_rebound_ = 0;
+  int64_t num_abandoned_passes_ = 0;
 };
 
 }  // namespace
 
 void bind_reducer(py::module_& m) {
   py::class_<GradReducer, std::shared_ptr<GradReducer>>(m, "GradReducer")
-      .def(py::init<std::vector<at::Tensor>, c10::intrusive_ptr<c10d::ProcessGroup>, int64_t, int64_t, bool, bool>(),
-           py::arg("params"), py::arg("process_group"), py::arg("bucket_cap_bytes"),
-           py::arg("first_bucket_bytes"), py::arg("force_collectives") = false, py::arg("reduce_fp32") = false)
+      .def(py::init<std::vector<at::Tensor>, std::shared_ptr<Communicator>, int64_t, int64_t, bool, bool, bool>(),
+           py::arg("params"), py::arg("communicator"), py::arg("bucket_cap_bytes"), py::arg("first_bucket_bytes"),
+           py::arg("force_collectives") = false, py::arg("reduce_fp32") = false, py::arg("decompose") = false)
       .def("set_sync", &GradReducer::set_sync)
       .def("sync_enabled", &GradReducer::sync_enabled)
       .def("remove_hooks", &GradReducer::remove_hooks)
       .def("zero_grad", &GradReducer::zero_grad)
+      .def("prepare_forward", &GradReducer::prepare_forward)
       .def("bucket_tensors", &GradReducer::bucket_tensors)
       .def("bucket_param_indices", &GradReducer::bucket_param_indices)
       .def_property_readonly("num_collectives", &GradReducer::num_collectives)
       .def_property_readonly("num_buckets", &GradReducer::num_buckets)
-      .def_property_readonly("num_rebound_grads", &GradReducer::num_rebound_grads);
+      .def_property_readonly("num_rebound_grads", &GradReducer::num_rebound_grads)
+      .def_property_readonly("num_abandoned_passes", &GradReducer::num_abandoned_passes);
 }

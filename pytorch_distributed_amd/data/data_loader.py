@@ -134,6 +134,18 @@ class KJJ0DataLoader:
         self.current_tokens: Optional[np.ndarray] = None
         self.current_position = 0
         self._h2d = _HostToDevice(device, self.batch_size * self.sequence_length + 1)
+        self._start_batch = 0   # batches to pass over at the start of the next iteration (resume)
+        self._yielded = 0       # batches handed out so far, including the ones passed over
+
+    # -- position (checkpoint / resume) --------------------------------------------------
+    def state_dict(self) -> dict:
+        """Position of the stream: the number of batches consumed. The stream is deterministic,
+        so this is all a resumed run needs to continue with the batch the interrupted one
+        would have seen next."""
+        return {"batches": self._yielded}
+
+    def load_state_dict(self, state: dict) -> None:
+        self._start_batch = int(state.get("batches", 0))
 
     # -- shard handling -----------------------------------------------------------------
     def _load_shard(self, filepath: str) -> np.ndarray:
@@ -167,6 +179,8 @@ class KJJ0DataLoader:
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         self._reset()
         B, T = self.batch_size, self.sequence_length
+        skip, self._start_batch = self._start_batch, 0
+        self._yielded = 0
         while True:
             pieces = []  # (window array, number of sequences) per shard touched by this batch
             need = B
@@ -178,9 +192,14 @@ class KJJ0DataLoader:
                     continue
                 take = min(avail, need)
                 pos = self.current_position
-                pieces.append((np.asarray(self.current_tokens[pos: pos + take * T + 1]), take))
+                if skip == 0:
+                    pieces.append((np.asarray(self.current_tokens[pos: pos + take * T + 1]), take))
                 self.current_position += take * T
                 need -= take
+            self._yielded += 1
+            if skip > 0:  # resuming: only the cursor moves (the shards are memory-mapped, nothing is read)
+                skip -= 1
+                continue
             if len(pieces) == 1:
                 buf = self._h2d.put(pieces[0][0])
                 yield buf[:-1].view(B, T), buf[1:].view(B, T)
@@ -212,13 +231,25 @@ class SyntheticTokenLoader:
         self.device = torch.device(device)
         self.num_batches = num_batches
         self.seed = seed
+        self._start_batch = 0
+        self._yielded = 0
+
+    def state_dict(self) -> dict:
+        return {"batches": self._yielded}
+
+    def load_state_dict(self, state: dict) -> None:
+        self._start_batch = int(state.get("batches", 0))
 
     def __iter__(self):
         gen = torch.Generator(device=self.device)
         gen.manual_seed(self.seed)
+        skip, self._start_batch = self._start_batch, 0
         n = 0
         while self.num_batches is None or n < self.num_batches:
             buf = torch.randint(0, self.vocab_size, (self.batch_size, self.sequence_length + 1),
                                 device=self.device, generator=gen)
-            yield buf[:, :-1].contiguous(), buf[:, 1:].contiguous()
             n += 1
+            self._yielded = n
+            if n <= skip:  # resuming: the generator is advanced past the batches already consumed
+                continue
+            yield buf[:, :-1].contiguous(), buf[:, 1:].contiguous()

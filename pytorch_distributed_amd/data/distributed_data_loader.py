@@ -50,7 +50,16 @@ class DistributedKJJ0DataLoader(KJJ0DataLoader):
         slots = [torch.empty(b * T + 1, dtype=torch.int64, pin_memory=on_gpu) for _ in range(4)]
         prefetcher = ext.TokenPrefetcher(self.files, b, T, self.rank, self.world_size, slots)
         in_flight = []  # (slot index, event recorded after its host-to-device copy)
+        skip, self._start_batch = self._start_batch, 0
+        self._yielded = 0
         try:
+            while skip > 0:  # resuming: windows already consumed are taken from the ring and dropped
+                idx = prefetcher.next()
+                if idx < 0:
+                    return
+                prefetcher.release(idx)
+                self._yielded += 1
+                skip -= 1
             while True:
                 # hand back slots whose copy has finished; if the ring is full wait for the oldest
                 while in_flight and (in_flight[0][1].query() or len(in_flight) >= len(slots) - 1):
@@ -68,6 +77,7 @@ class DistributedKJJ0DataLoader(KJJ0DataLoader):
                 else:
                     buf = slots[idx].clone()
                     prefetcher.release(idx)
+                self._yielded += 1
                 yield buf[:-1].view(b, T), buf[1:].view(b, T)
         finally:
             prefetcher.stop()
@@ -79,12 +89,18 @@ class DistributedKJJ0DataLoader(KJJ0DataLoader):
         self._reset()
         b, T, W = self.local_batch_size, self.sequence_length, self.world_size
         local = b * T
+        skip, self._start_batch = self._start_batch, 0
+        self._yielded = 0
         while True:
             while self.current_tokens is None or self.current_position + W * local >= len(self.current_tokens):
                 if not self._advance_shard():
                     return
             start = self.current_position + self.rank * local
-            window = np.asarray(self.current_tokens[start: start + local + 1])
             self.current_position += W * local
+            self._yielded += 1
+            if skip > 0:  # resuming: only the cursor moves
+                skip -= 1
+                continue
+            window = np.asarray(self.current_tokens[start: start + local + 1])
             buf = self._h2d.put(window)
             yield buf[:-1].view(b, T), buf[1:].view(b, T)

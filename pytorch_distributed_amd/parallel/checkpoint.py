@@ -6,14 +6,18 @@ parameter names, ``optimizer_state_dict`` in ``torch.optim.AdamW`` layout indexe
 model's ``parameters()`` order, ``step`` and ``lr_scheduler_state_dict``. Under sharding both
 dictionaries are gathered collectively (``FSDP.state_dict`` and ``full_optim_state_dict``
 below) and only rank 0 writes, so the file loads into the reference's ``Trainer`` and a
-reference checkpoint loads into a sharded model at any world size.
+reference checkpoint loads into a sharded model at any world size. The gathered model values
+are the fp32 MASTER weights (not the bf16 compute copies), so save -> resume of a bf16 run
+continues bit-exactly.
 
 Sharded format — one file per rank, ``rank{r}_of_{W}.pt``, holding this rank's fp32 flat
 shards and optimizer moments per communication unit plus the layout needed to interpret
 them (parameter names, shapes, offsets, shard size), and a ``meta.json`` written by rank 0.
-Saving and loading are local (no collective, no full copy on any rank): the form for the
-7B-class models. ``consolidate_sharded_checkpoint`` turns a sharded checkpoint directory into
-the full format offline, which is also how a checkpoint moves to a different world size.
+Saving is local (no collective, no full copy on any rank): the form for the 7B-class models.
+Loading at the saved world size is local too; at a DIFFERENT world size every rank re-slices
+its new shard ranges out of the saved files that overlap them (``load_sharded_checkpoint``
+reads only those). ``consolidate_sharded_checkpoint`` turns a sharded checkpoint directory
+into the full format offline.
 """
 from __future__ import annotations
 
@@ -22,7 +26,8 @@ import os
 from typing import Dict, List, Optional
 
 import torch
-import torch.distributed as dist
+
+from . import comm
 
 STATE_KEYS = ("exp_avg", "exp_avg_sq")
 
@@ -70,14 +75,84 @@ def unit_layouts(model) -> List[dict]:
     return layouts
 
 
+# ------------------------------------------------------------------ full model state
+def full_model_state_dict(model, cpu_offload: bool = True, rank0_only: bool = False) -> dict:
+    """The bare model's ``state_dict()`` (same keys, same order, tied aliases included) with every
+    parameter taken from the gathered fp32 master shards. Collective: every rank must call it."""
+    owner = {}
+    for u in _units(model):
+        for i, p in enumerate(u._unit_params):
+            owner[id(p)] = (u, i)
+    gathered = {}
+    out = {}
+    made = {}  # tied parameters appear under several keys and share one tensor, as in the bare model
+    keep = not (rank0_only and model.rank != 0)
+    for k, v in model.module.state_dict(keep_vars=True).items():
+        k = k.replace("module.", "")
+        if id(v) in owner:
+            u, i = owner[id(v)]
+            if id(u) not in gathered:  # one collective per unit, in unit order on every rank
+                gathered[id(u)] = u.unit.gather_shards(u.unit.shard_master())
+            if not keep:
+                continue
+            if id(v) not in made:
+                off = u.unit.offsets()[i]
+                t = gathered[id(u)][off: off + v.numel()].view(v.shape)
+                made[id(v)] = t.cpu() if cpu_offload else t.clone()
+            out[k] = made[id(v)]
+        elif keep:
+            t = v.detach()
+            out[k] = t.cpu() if cpu_offload else t.clone()
+    return out
+
+
+def load_full_model_state_dict(model, state_dict: dict, strict: bool = True):
+    """Inverse: every rank passes the same full state dict; each unit's fp32 master shard (and
+    its low-precision mirror) is cut straight out of it — nothing passes through bf16."""
+    state_dict = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+    names = _param_names(model)
+    used = set()
+    missing = []
+    with torch.no_grad():
+        for u in _units(model):
+            flat = torch.zeros(u.unit.padded_numel, dtype=torch.float32, device=u.flat_param.device)
+            current = None
+            for p, off in zip(u._unit_params, u.unit.offsets()):
+                name = names[id(p)]
+                if name in state_dict:
+                    src = state_dict[name]
+                    if tuple(src.shape) != tuple(p.shape):
+                        raise RuntimeError(f"size mismatch for {name}: checkpoint {tuple(src.shape)}, "
+                                           f"model {tuple(p.shape)}")
+                    flat[off: off + p.numel()].copy_(src.reshape(-1))
+                    used.add(name)
+                else:
+                    missing.append(name)
+                    if current is None:  # keep the present values of parameters the file lacks
+                        current = u.unit.gather_shards(u.unit.shard_master())
+                    flat[off: off + p.numel()].copy_(current[off: off + p.numel()])
+            u.unit.load_master_from_full(flat)
+        # tied aliases and buffers
+        own = model.module.state_dict(keep_vars=True)
+        param_ids = {id(p) for u in _units(model) for p in u._unit_params}
+        unexpected = []
+        for k, v in state_dict.items():
+            if k in used:
+                continue
+            kk = next((o for o in own if o.replace("module.", "") == k), None)
+            if kk is None:
+                unexpected.append(k)
+            elif id(own[kk]) not in param_ids:
+                own[kk].copy_(v)
+    if strict and (missing or unexpected):
+        raise RuntimeError(f"load_state_dict: missing keys {missing}, unexpected keys {unexpected}")
+    return missing, unexpected
+
+
 # ------------------------------------------------------------------ full optimizer state
-def _gather_flat(shard: torch.Tensor, unit, group) -> torch.Tensor:
+def _gather_flat(shard: torch.Tensor, unit) -> torch.Tensor:
     """All ranks' shards of one flat tensor, concatenated (collective unless replicated)."""
-    if unit.unit.padded_numel == unit.unit.shard_numel or dist.get_world_size(group) == 1:
-        return shard
-    full = torch.empty(unit.unit.padded_numel, dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(full, shard.contiguous(), group=group)
-    return full
+    return unit.unit.gather_shards(shard.reshape(-1))
 
 
 def full_optim_state_dict(model, optimizer, cpu_offload: bool = True) -> dict:
@@ -89,7 +164,7 @@ def full_optim_state_dict(model, optimizer, cpu_offload: bool = True) -> dict:
         st = optimizer.state.get(u.flat_param, {})
         if "exp_avg" not in st:
             continue
-        fulls = {k: _gather_flat(st[k].view(-1), u, u.process_group) for k in STATE_KEYS}
+        fulls = {k: _gather_flat(st[k], u) for k in STATE_KEYS}
         step = st["step"]
         for p, off in zip(u._unit_params, u.unit.offsets()):
             entry = {"step": torch.as_tensor(float(step), dtype=torch.float32)}
@@ -138,8 +213,7 @@ def load_full_optim_state_dict(model, optimizer, full_state: dict) -> None:
 def save_sharded_checkpoint(directory: str, model, optimizer=None, step: int = 0, lr_scheduler=None) -> str:
     """Writes this rank's shards to ``directory/rank{r}_of_{W}.pt`` (no collective)."""
     os.makedirs(directory, exist_ok=True)
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank, world = comm.get_rank(), comm.get_world_size()
     layouts = unit_layouts(model)
     units = []
     for u in _units(model):
@@ -162,40 +236,93 @@ def save_sharded_checkpoint(directory: str, model, optimizer=None, step: int = 0
     if rank == 0:
         with open(os.path.join(directory, "meta.json"), "w") as f:
             json.dump({"format": "pda-sharded-v1", "world_size": world, "step": step, "layouts": layouts}, f)
-    if dist.is_initialized() and world > 1:
-        dist.barrier()
+    comm.barrier()
     return path
 
 
-def load_sharded_checkpoint(directory: str, model, optimizer=None, lr_scheduler=None) -> int:
-    """Loads this rank's file written by :func:`save_sharded_checkpoint` at the SAME world size
-    and wrapping. Returns the saved step."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    path = os.path.join(directory, f"rank{rank}_of_{world}.pt")
+def _load_rank_file(directory: str, r: int, world: int) -> dict:
+    path = os.path.join(directory, f"rank{r}_of_{world}.pt")
     if not os.path.exists(path):
-        raise FileNotFoundError(f"{path} not found: a sharded checkpoint only loads at the world size it was "
-                                "saved with; use consolidate_sharded_checkpoint() to move it")
-    payload = torch.load(path, map_location="cpu", weights_only=True)
+        raise FileNotFoundError(f"{path} not found (incomplete sharded checkpoint?)")
+    return torch.load(path, map_location="cpu", weights_only=True, mmap=True)
+
+
+def _restore_unit(u, shard: torch.Tensor, optim: Optional[dict], optimizer) -> None:
+    with torch.no_grad():
+        u.flat_param.copy_(shard.view(u.flat_param.shape))
+        lowp = getattr(u.flat_param, "_pda_lowp", None)
+        if lowp is not None:
+            if lowp.numel() == u.flat_param.numel():
+                lowp.copy_(u.flat_param)
+            else:  # NO_SHARD: the mirror is the whole live buffer
+                lowp.view(-1)[: u.flat_param.numel()].copy_(u.flat_param)
+    if optimizer is not None and optim is not None:
+        st = optimizer.state[u.flat_param]
+        st["step"] = torch.tensor(optim["step"], dtype=torch.float32)
+        for k in STATE_KEYS:
+            st[k] = optim[k].to(u.flat_param.device).view(u.flat_param.shape).clone()
+
+
+def load_sharded_checkpoint(directory: str, model, optimizer=None, lr_scheduler=None) -> int:
+    """Loads a checkpoint written by :func:`save_sharded_checkpoint`. At the saved world size this
+    is one local file read per rank; at any other world size (or sharding strategy) every rank
+    cuts its new shard ranges out of the saved rank files that overlap them. The unit layout
+    (which parameters form a unit, in which order) must be the one that was saved. Returns the
+    saved step."""
+    rank, world = comm.get_rank(), comm.get_world_size()
+    with open(os.path.join(directory, "meta.json")) as f:
+        meta = json.load(f)
+    saved_world = int(meta["world_size"])
     units = _units(model)
-    if len(units) != len(payload["units"]):
-        raise ValueError("sharded checkpoint was saved with a different unit layout")
-    for u, saved, layout in zip(units, payload["units"], payload["layouts"]):
-        if layout["shard_numel"] != u.unit.shard_numel:
-            raise ValueError("sharded checkpoint shard size differs from the model's")
-        with torch.no_grad():
-            u.flat_param.copy_(saved["shard"])
-            lowp = getattr(u.flat_param, "_pda_lowp", None)
-            if lowp is not None:
-                if lowp.numel() == u.flat_param.numel():
-                    lowp.copy_(u.flat_param)
-                else:  # NO_SHARD: the mirror is the whole live buffer
-                    lowp.view(-1)[: u.flat_param.numel()].copy_(u.flat_param)
-        if optimizer is not None and "optim" in saved:
-            st = optimizer.state[u.flat_param]
-            st["step"] = torch.tensor(saved["optim"]["step"], dtype=torch.float32)
-            for k in STATE_KEYS:
-                st[k] = saved["optim"][k].to(u.flat_param.device).view(u.flat_param.shape).clone()
+    layouts = meta["layouts"]
+    if len(units) != len(layouts):
+        raise ValueError("sharded checkpoint was saved with a different unit layout "
+                         f"({len(layouts)} units, the model has {len(units)})")
+    mine = unit_layouts(model)
+    for now, then in zip(mine, layouts):
+        if now["names"] != then["names"] or now["offsets"] != then["offsets"]:
+            raise ValueError("sharded checkpoint was saved with a different unit layout; "
+                             "consolidate_sharded_checkpoint() converts it to the full format")
+    same = saved_world == world and all(a["shard_numel"] == b["shard_numel"] and a["padded_numel"] == b["padded_numel"]
+                                        for a, b in zip(mine, layouts))
+    cache: Dict[int, dict] = {}
+
+    def rank_file(r: int) -> dict:
+        if r not in cache:
+            cache[r] = _load_rank_file(directory, r, saved_world)
+        return cache[r]
+
+    if same:
+        payload = rank_file(rank)
+        for u, saved in zip(units, payload["units"]):
+            _restore_unit(u, saved["shard"], saved.get("optim") if optimizer is not None else None, optimizer)
+    else:
+        for ui, (u, then) in enumerate(zip(units, layouts)):
+            n_new, idx = u.unit.shard_numel, u.unit.shard_index
+            lo, hi = idx * n_new, (idx + 1) * n_new           # my range of the unit's flat layout
+            n_old = then["shard_numel"]
+            replicated_then = then["padded_numel"] == then["shard_numel"]
+            bufs = {"shard": torch.zeros(n_new, dtype=torch.float32)}
+            have_opt, step = optimizer is not None, 0.0
+            first = 0 if replicated_then else lo // n_old
+            last = 0 if replicated_then else min((hi - 1) // n_old, saved_world - 1)
+            for r in range(first, last + 1):
+                saved = rank_file(r)["units"][ui]
+                o_lo = 0 if replicated_then else r * n_old
+                a, b = max(lo, o_lo), min(hi, o_lo + n_old)
+                if b <= a:
+                    continue
+                bufs["shard"][a - lo: b - lo].copy_(saved["shard"].view(-1)[a - o_lo: b - o_lo])
+                if have_opt and "optim" in saved:
+                    step = saved["optim"]["step"]
+                    for k in STATE_KEYS:
+                        bufs.setdefault(k, torch.zeros(n_new, dtype=torch.float32))
+                        bufs[k][a - lo: b - lo].copy_(saved["optim"][k].view(-1)[a - o_lo: b - o_lo])
+                else:
+                    have_opt = False
+            optim = {"step": step, **{k: bufs[k] for k in STATE_KEYS}} if have_opt and "exp_avg" in bufs else None
+            _restore_unit(u, bufs["shard"], optim, optimizer)
+    payload = rank_file(rank if same else 0)
     if optimizer is not None and "param_groups" in payload:
         for g, sg in zip(optimizer.param_groups, payload["param_groups"]):
             g.update(sg)

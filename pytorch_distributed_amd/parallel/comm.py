@@ -1,23 +1,39 @@
-"""Process-group bootstrap and small collective helpers.
+"""Bootstrap of the framework's own communicator and small collective helpers.
 
 One process per GPU, launched by ``torchrun`` (``RANK`` / ``WORLD_SIZE`` / ``LOCAL_RANK`` /
 ``MASTER_ADDR`` / ``MASTER_PORT`` in the environment, as the reference's scripts expect:
-assignments/assignment1/train_ddp.py:23-36). On GPUs the backend is ``"nccl"``, which on ROCm
-is RCCL over xGMI; without a GPU it is ``"gloo"``, so every distributed code path of this
-package also runs in CPU-only tests — the reference hard-codes ``'nccl'`` and cannot.
+assignments/assignment1/train_ddp.py:23-36). ``init_distributed()`` builds ONE native
+communicator (``csrc/runtime/comm``) from that environment and every layer above — the gradient
+reducer, the sharding units, the trainers, the checkpoint code — talks to it:
 
-Beyond the reference: collectives get a finite timeout (a rank that dies turns into an
-error on its peers instead of a hang), and ``PDA_COMM_DEBUG=1`` cross-checks bulk
-collectives between ranks before they are issued.
+* ``"rccl"``   GPUs: an RCCL communicator the framework creates itself (unique id published by
+  rank 0 in the framework's TCP store, ``ncclCommInitRank``), two HIP streams of its own (one
+  for all-gathers, one for reductions), event fences against the compute stream, a watchdog
+  that aborts the communicator when a collective exceeds the timeout.
+* ``"socket"`` CPUs: the same interface over a TCP mesh, so every distributed code path also
+  runs without a GPU — the reference hard-codes ``'nccl'`` and cannot.
+* ``"c10d"``   an existing ``torch.distributed`` process group wrapped in the same interface,
+  for callers that already own one (never created by default).
+
+``torch.distributed`` is not initialised by this module unless ``backend="c10d"`` is requested.
+
+Debugging: ``PDA_COMM_DEBUG=1`` cross-checks every bulk collective between ranks before it is
+issued, ``PDA_COMM_SERIALIZE=1`` removes all overlap (``csrc/runtime/comm_debug.h``).
 """
 from __future__ import annotations
 
 import datetime
 import os
-from typing import Optional, Tuple
+import struct
+from typing import List, Optional, Tuple
 
 import torch
-import torch.distributed as dist
+
+from .. import _ext
+
+_COMM = None          # the process-wide communicator
+_DEVICE = None
+_OWNS_C10D = False
 
 
 def env_rank_world() -> Tuple[int, int, int]:
@@ -25,67 +41,222 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", 0)))
 
 
-def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) -> Tuple[int, int, torch.device]:
-    """Initialises the default process group from the torchrun environment.
+def _store_port() -> int:
+    """Port of the framework's rendezvous store: next to the launcher's MASTER_PORT (which the
+    launcher's own store occupies); the native client scans upwards from it when it is taken."""
+    if "PDA_STORE_PORT" in os.environ:
+        return int(os.environ["PDA_STORE_PORT"])
+    return int(os.environ.get("MASTER_PORT", "29500")) + 1
 
+
+def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) -> Tuple[int, int, torch.device]:
+    """Creates the process-wide communicator from the torchrun environment.
+
+    ``backend``: ``"rccl"`` (alias ``"nccl"``), ``"socket"`` (alias ``"gloo"``: the CPU backend),
+    ``"c10d"`` or None = RCCL when a GPU is visible, the socket mesh otherwise.
     Returns ``(rank, world_size, device)``. Safe to call when already initialised.
     """
+    global _COMM, _DEVICE, _OWNS_C10D
     rank, world, local_rank = env_rank_world()
-    use_gpu = torch.cuda.is_available() and backend != "gloo"
+    if _COMM is not None:
+        return _COMM.rank, _COMM.world_size, _DEVICE
+    backend = {"nccl": "rccl", "gloo": "socket", None: None}.get(backend, backend)
     if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
-    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
-    if use_gpu:
+        backend = os.environ.get("PDA_COMM_BACKEND") or ("rccl" if torch.cuda.is_available() else "socket")
+    ext = _ext.require()
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    job = os.environ.get("PDA_JOB_ID") or f"{host}:{os.environ.get('MASTER_PORT', '29500')}"
+    if backend == "rccl":
+        if not torch.cuda.is_available():
+            raise RuntimeError("the 'rccl' communicator needs a GPU; use backend='socket' on CPUs")
+        device = torch.device("cuda", local_rank)
         torch.cuda.set_device(device)
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        kwargs = dict(backend=backend, rank=rank, world_size=world,
-                      timeout=datetime.timedelta(seconds=timeout_s))
+        torch.zeros(1, device=device)  # the HIP context exists before RCCL initialises
+        _COMM = ext.create_communicator("rccl", rank, world, host, _store_port(), local_rank, timeout_s, job)
+    elif backend == "socket":
+        device = torch.device("cpu")
+        _COMM = ext.create_communicator("socket", rank, world, host, _store_port(), 0, timeout_s, job)
+    elif backend == "c10d":
+        import torch.distributed as dist
+
+        use_gpu = torch.cuda.is_available()
+        device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
         if use_gpu:
-            kwargs["device_id"] = device  # binds the communicator to this GPU at init time
-        dist.init_process_group(**kwargs)
+            torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            kwargs = dict(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world,
+                          timeout=datetime.timedelta(seconds=timeout_s))
+            if use_gpu:
+                kwargs["device_id"] = device
+            dist.init_process_group(**kwargs)
+            _OWNS_C10D = True
+        _COMM = ext.wrap_process_group(dist.distributed_c10d._get_default_group())
+    else:
+        raise ValueError(f"unknown communicator backend {backend!r} (rccl, socket, c10d)")
+    _DEVICE = device
     if rank == 0:
-        print(f"Initialized process group: world_size={world}, backend={backend}")
+        extra = f", RCCL {_COMM.rccl_version()}" if backend == "rccl" else ""
+        print(f"Initialized process group: world_size={world}, backend={_COMM.backend}{extra}")
     return rank, world, device
 
 
+def set_communicator(comm, device=None) -> None:
+    """Installs an externally built communicator (tests: a recording decorator) as the process-wide one."""
+    global _COMM, _DEVICE
+    _COMM = comm
+    if device is not None:
+        _DEVICE = torch.device(device)
+    elif _DEVICE is None:
+        _DEVICE = torch.device("cuda", torch.cuda.current_device()) if comm.on_gpu else torch.device("cpu")
+
+
 def shutdown() -> None:
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    """Counterpart of the reference's ``dist.destroy_process_group()`` (train_ddp.py:146)."""
+    global _COMM, _DEVICE, _OWNS_C10D
+    if _COMM is not None and _COMM.on_gpu and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _COMM = None
+    _DEVICE = None
+    if _OWNS_C10D:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        _OWNS_C10D = False
 
 
-def default_group():
-    """The default ProcessGroup object (what the C++ reducer / sharding units take), or None."""
-    if not dist.is_initialized():
-        return None
-    return dist.distributed_c10d._get_default_group()
+def is_initialized() -> bool:
+    return _COMM is not None
+
+
+def get_communicator():
+    """The process-wide native communicator (what the C++ reducer / sharding units take), or None."""
+    return _COMM
+
+
+def resolve(communicator=None, process_group=None):
+    """The communicator a wrapper should use: an explicit one, a torch process group wrapped in
+    the native interface, or the process-wide default."""
+    if communicator is not None:
+        return communicator
+    if process_group is not None:
+        return _ext.require().wrap_process_group(process_group)
+    if _COMM is None:
+        raise RuntimeError("no communicator: call pytorch_distributed_amd.parallel.init_distributed() first")
+    return _COMM
+
+
+def get_rank() -> int:
+    return _COMM.rank if _COMM is not None else 0
+
+
+def get_world_size() -> int:
+    return _COMM.world_size if _COMM is not None else 1
+
+
+def comm_device() -> torch.device:
+    return _DEVICE if _DEVICE is not None else torch.device("cpu")
+
+
+def barrier() -> None:
+    if _COMM is not None and _COMM.world_size > 1:
+        _COMM.barrier()
 
 
 def comm_debug() -> bool:
     return os.environ.get("PDA_COMM_DEBUG", "0") == "1"
 
 
-def assert_same_across_ranks(values, what: str, group=None) -> None:
+def assert_same_across_ranks(values, what: str, communicator=None) -> None:
     """Debug check: every rank must hold the same list of integers (shapes, counts, ...)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    c = communicator if communicator is not None else _COMM
+    if c is None or c.world_size == 1:
         return
-    mine = torch.tensor(list(values), dtype=torch.int64)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
-    mine = mine.to(dev)
-    gathered = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(gathered, mine, group=group)
-    for r, other in enumerate(gathered):
-        if not torch.equal(other, mine):
-            raise RuntimeError(f"{what} differs between rank {dist.get_rank(group)} and rank {r}: "
-                               f"{mine.tolist()[:8]}... vs {other.tolist()[:8]}...")
+    mine = list(int(v) for v in values)
+    blob = struct.pack(f"<{len(mine)}q", *mine)
+    for r, other in enumerate(c.exchange(blob)):
+        if other != blob:
+            theirs = list(struct.unpack(f"<{len(other) // 8}q", other))
+            raise RuntimeError(f"{what} differs between rank {c.rank} and rank {r}: "
+                               f"{mine[:8]}... vs {theirs[:8]}...")
 
 
-def all_reduce_mean_scalar(value: float, device) -> float:
-    """Mean of a host scalar over all ranks (the logging all-reduce of the reference,
-    assignments/assignment1/train/distributed_trainer.py:131-154)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def all_reduce(t: torch.Tensor, op: str = "sum", communicator=None) -> torch.Tensor:
+    """In-place all-reduce of ``t`` (blocking for the caller's stream)."""
+    c = communicator if communicator is not None else _COMM
+    if c is None or c.world_size == 1:
+        return t
+    c.all_reduce(t, op).wait()
+    return t
+
+
+def broadcast(t: torch.Tensor, root: int = 0, communicator=None) -> torch.Tensor:
+    c = communicator if communicator is not None else _COMM
+    if c is None or c.world_size == 1:
+        return t
+    c.broadcast(t, root).wait()
+    return t
+
+
+def broadcast_coalesced(tensors: List[torch.Tensor], root: int = 0, communicator=None,
+                        chunk_bytes: int = 256 * 2**20) -> None:
+    """Rank ``root``'s values into every rank's tensors, packed into flat buffers of at most
+    ``chunk_bytes`` per dtype (the initial parameter broadcast of DDP)."""
+    c = communicator if communicator is not None else _COMM
+    if c is None or c.world_size == 1 or not tensors:
+        return
+    def flush(batch):
+        if not batch:
+            return
+        flat = torch.cat([b.reshape(-1) for b in batch])
+        c.broadcast(flat, root).wait()
+        off = 0
+        for b in batch:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+    with torch.no_grad():
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for group in by_dtype.values():
+            batch, size = [], 0
+            for t in group:
+                nbytes = t.numel() * t.element_size()
+                if batch and size + nbytes > chunk_bytes:
+                    flush(batch)
+                    batch, size = [], 0
+                batch.append(t)
+                size += nbytes
+            flush(batch)
+
+
+class LazyScalarMean:
+    """Mean of a device scalar over all ranks, issued now on the reduction queue and read later.
+
+    The logging all-reduce of the reference (assignments/assignment1/train/distributed_trainer.py:131-154)
+    blocks every rank on a 4-byte collective; here it rides the side stream and the host only
+    waits when the value is printed."""
+
+    def __init__(self, value: torch.Tensor, communicator=None):
+        c = communicator if communicator is not None else _COMM
+        self._t = value.detach().reshape(1).to(torch.float32).clone()
+        self._work = None
+        if c is not None and c.world_size > 1:
+            self._work = c.all_reduce(self._t, "avg", 1)
+
+    def value(self) -> float:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return float(self._t.item())
+
+
+def all_reduce_mean_scalar(value: float, device=None) -> float:
+    """Mean of a host scalar over all ranks."""
+    if _COMM is None or _COMM.world_size == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float32, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item()) / dist.get_world_size()
+    t = torch.tensor([value], dtype=torch.float32, device=device if device is not None else comm_device())
+    return LazyScalarMean(t).value()

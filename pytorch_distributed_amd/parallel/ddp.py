@@ -7,9 +7,11 @@
 checkpoints load into the bare model and vice versa.
 
 All per-gradient work happens in C++ (``csrc/runtime/reducer.cpp``): gradients are views of
-flat buckets, buckets are all-reduced over RCCL from autograd hooks while backward is
-still running, and the optimizer is fenced behind the collectives by an end-of-backward
-stream wait. Not reproduced from torch DDP because the model gives it no purpose: the
+flat buckets, buckets are reduced on the native communicator's reduction stream
+(``csrc/runtime/comm``: RCCL on GPUs, the TCP mesh on CPUs) from autograd hooks while backward
+is still running, and the optimizer is fenced behind the collectives by an end-of-backward
+stream wait. ``bucket_cap_mb=None`` / ``decompose=None`` take the values the start-up
+measurement chose (``parallel/autotune.py``); explicit values always win. Not reproduced from torch DDP because the model gives it no purpose: the
 per-forward buffer broadcast (this GPT-2 has no buffers — the reference's ``causal_mask``
 buffers cost 36 MiB of broadcast per forward) and the unused-parameter graph search
 (buckets whose parameters got no gradient are simply flushed at the end of backward).
@@ -21,7 +23,6 @@ import functools
 from typing import Optional
 
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from .. import _ext
@@ -39,17 +40,18 @@ def _bucket_slot(p):
 
 class DDP(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
-                 bucket_cap_mb: float = DEFAULT_BUCKET_CAP_MB, first_bucket_mb: float = DEFAULT_FIRST_BUCKET_MB,
-                 broadcast_parameters: bool = True, force_collectives: bool = False, reduce_fp32: bool = False):
+                 bucket_cap_mb: Optional[float] = None, first_bucket_mb: float = DEFAULT_FIRST_BUCKET_MB,
+                 broadcast_parameters: bool = True, force_collectives: bool = False, reduce_fp32: bool = False,
+                 decompose: Optional[bool] = None, communicator=None):
         """``reduce_fp32``: all-reduce bf16 gradient buckets through an fp32 copy (twice the bytes on
-        the wire, no rounding between the ranks' contributions); default: the gradient dtype."""
+        the wire, no rounding between the ranks' contributions); default: the gradient dtype.
+        ``decompose``: reduce each bucket as reduce-scatter + all-gather instead of one all-reduce.
+        ``process_group``: a torch.distributed group to run on instead of the native communicator."""
         super().__init__()
-        if not dist.is_initialized():
-            raise RuntimeError("DDP needs an initialised process group (parallel.init_distributed())")
         self.module = module
-        self.process_group = process_group if process_group is not None else comm.default_group()
-        self.world_size = dist.get_world_size(self.process_group)
-        self.rank = dist.get_rank(self.process_group)
+        self.communicator = comm.resolve(communicator, process_group)
+        self.world_size = self.communicator.world_size
+        self.rank = self.communicator.rank
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise ValueError("DDP: the module has no trainable parameters")
@@ -58,20 +60,27 @@ class DDP(nn.Module):
             if params[0].device != want:
                 raise ValueError(f"DDP: module lives on {params[0].device}, device_ids says {want}")
         self._params = params
-        if params[0].is_cuda and dist.get_backend(self.process_group) == "gloo":
-            # gloo's device-tensor all-reduce stalls intermittently under the reducer's overlapped
-            # launches (measured with two ranks on one GPU); GPU tensors go over RCCL.
-            raise RuntimeError("DDP on GPU tensors needs the 'nccl' (RCCL) backend, not gloo")
+        if params[0].is_cuda != self.communicator.on_gpu:
+            raise RuntimeError(f"DDP: the '{self.communicator.backend}' communicator cannot move "
+                               f"{'GPU' if params[0].is_cuda else 'CPU'} tensors")
+
+        from . import autotune
+        tuned = autotune.current_policy()
+        if bucket_cap_mb is None:
+            bucket_cap_mb = tuned.ddp_bucket_mb if tuned is not None else DEFAULT_BUCKET_CAP_MB
+        if decompose is None:
+            decompose = tuned.ddp_decompose if tuned is not None else False
+        self.bucket_cap_mb, self.decompose = float(bucket_cap_mb), bool(decompose)
 
         # Same shapes everywhere, then rank 0's values everywhere (parameters and buffers).
-        comm.assert_same_across_ranks([p.numel() for p in params], "parameter sizes", self.process_group)
+        comm.assert_same_across_ranks([p.numel() for p in params], "parameter sizes", self.communicator)
         if broadcast_parameters and self.world_size > 1:
             tensors = [p.data for p in params] + [b.data for b in module.buffers()]
-            dist._broadcast_coalesced(self.process_group, tensors, 256 * 1024 * 1024, 0)
+            comm.broadcast_coalesced(tensors, 0, self.communicator)
 
         ext = _ext.require()
-        self.reducer = ext.GradReducer(params, self.process_group, int(bucket_cap_mb * 2**20),
-                                       int(first_bucket_mb * 2**20), force_collectives, reduce_fp32)
+        self.reducer = ext.GradReducer(params, self.communicator, int(bucket_cap_mb * 2**20),
+                                       int(first_bucket_mb * 2**20), force_collectives, reduce_fp32, self.decompose)
         for p in params:
             p._pda_grad_is_view = True  # optimizers must zero these in place, never drop them
             # ops.linear / ops.norm add their parameter gradients straight into the bucket view
@@ -81,6 +90,7 @@ class DDP(nn.Module):
 
     # -- module surface ----------------------------------------------------------------
     def forward(self, *args, **kwargs):
+        self.reducer.prepare_forward()  # closes a pass left open by a backward that raised
         return self.module(*args, **kwargs)
 
     @property

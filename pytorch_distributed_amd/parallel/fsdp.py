@@ -13,11 +13,13 @@ Strategies: FULL_SHARD (parameters, gradients, optimizer state sharded; all-gath
 unit's forward and backward, reduce-scatter after its backward), SHARD_GRAD_OP (parameters
 stay unsharded from forward to the end of backward), NO_SHARD (replicated; all-reduce).
 
-The mechanics live in C++ (``csrc/runtime/fsdp_unit.cpp``). This module only decides WHEN:
-module forward hooks unshard a unit and prefetch the next ones, a tensor hook on a unit's
-output does the same for backward in reverse order, and everything after that (gradient
-gathering, reduce-scatter launch, resharding, end-of-backward fence) is driven by the
-native autograd hooks.
+The mechanics AND the schedule live in C++ (``csrc/runtime/fsdp_unit.cpp``). The module's
+forward hooks make one native call each (``ShardedRuntime.pre_forward`` unshards the unit and
+prefetches the next ones; ``post_forward`` reshards and plants C++ gradient hooks on the unit's
+outputs), and the whole backward — re-gathering parameters in reverse order with prefetch,
+gradient gathering, reduce-scatter launch, resharding, end-of-backward fence — runs from native
+autograd hooks without entering Python. Collectives go through the native communicator
+(``csrc/runtime/comm``): all-gathers on its gather stream, reductions on its reduce stream.
 """
 from __future__ import annotations
 
@@ -28,7 +30,6 @@ import enum
 from typing import Dict, Iterator, List, Optional, Tuple
 
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from .. import _ext
@@ -57,25 +58,22 @@ class FSDP(nn.Module):
 
     def __init__(self, module: nn.Module, sharding_strategy=ShardingStrategy.FULL_SHARD,
                  process_group=None, forward_prefetch: int = 1, backward_prefetch: int = 1,
-                 force_collectives: bool = False, reduce_fp32: bool = False):
+                 force_collectives: bool = False, reduce_fp32: bool = False, communicator=None):
         """``reduce_fp32``: reduce bf16 gradients through an fp32 copy (twice the bytes on the wire,
-        no rounding between the ranks' contributions); the default reduces in the gradient dtype."""
+        no rounding between the ranks' contributions); the default reduces in the gradient dtype.
+        ``process_group``: a torch.distributed group to run on instead of the native communicator."""
         super().__init__()
-        if not dist.is_initialized():
-            raise RuntimeError("FSDP needs an initialised process group (parallel.init_distributed())")
         self.module = module
         self.sharding_strategy = _as_strategy(sharding_strategy)
-        self.process_group = process_group if process_group is not None else comm.default_group()
-        self.world_size = dist.get_world_size(self.process_group)
-        self.rank = dist.get_rank(self.process_group)
+        self.communicator = comm.resolve(communicator, process_group)
+        self.world_size = self.communicator.world_size
+        self.rank = self.communicator.rank
         self.forward_prefetch = forward_prefetch
         self.backward_prefetch = backward_prefetch
         first = next((p for p in module.parameters() if p.requires_grad), None)
-        if first is not None and first.is_cuda and dist.get_backend(self.process_group) == "gloo":
-            # gloo's device-tensor collectives pin the buffers they were given on streams of their
-            # own; with the units' release-and-reallocate storage a second backward stalls in them
-            # (measured). GPU tensors go over RCCL.
-            raise RuntimeError("FSDP on GPU tensors needs the 'nccl' (RCCL) backend, not gloo")
+        if first is not None and first.is_cuda != self.communicator.on_gpu:
+            raise RuntimeError(f"FSDP: the '{self.communicator.backend}' communicator cannot move "
+                               f"{'GPU' if first.is_cuda else 'CPU'} tensors")
 
         # Parameters already owned by nested FSDP instances stay with them.
         nested = [m for m in module.modules() if isinstance(m, FSDP)]
@@ -91,10 +89,10 @@ class FSDP(nn.Module):
             raise ValueError("FSDP: nothing to shard in this module (all parameters belong to nested units)")
         self._unit_params: List[nn.Parameter] = mine
         self._unit_param_names = names
-        comm.assert_same_across_ranks([p.numel() for p in mine], "FSDP unit parameter sizes", self.process_group)
+        comm.assert_same_across_ranks([p.numel() for p in mine], "FSDP unit parameter sizes", self.communicator)
 
         ext = _ext.require()
-        self.unit = ext.ShardedUnit(mine, self.process_group, self.sharding_strategy.value, force_collectives,
+        self.unit = ext.ShardedUnit(mine, self.communicator, self.sharding_strategy.value, force_collectives,
                                     reduce_fp32)
         # Weight matrices hand ops.linear a slice of this unit's flat gradient buffer, so the
         # weight-gradient kernel writes there directly instead of producing a tensor that the
@@ -136,7 +134,8 @@ class FSDP(nn.Module):
         # of forward and of backward: it stays unsharded from its first use to the end.
         self.unit.reshard_after_forward = False
         self._order = units
-        self._runtime = _ext.require().ShardedRuntime([u.unit for u in units])
+        self._runtime = _ext.require().ShardedRuntime([u.unit for u in units], self.forward_prefetch,
+                                                      self.backward_prefetch)
 
     # ------------------------------------------------------------------ hooks
     def _units(self) -> List["FSDP"]:
@@ -145,67 +144,17 @@ class FSDP(nn.Module):
     def _pre_forward(self, module, args, kwargs):
         if self._is_root is None:
             self._lazy_init_root()
-        root = self._root or self
-        self.unit.unshard()
-        order = root._order
-        if not root._runtime.in_backward():
-            for k in range(1, self.forward_prefetch + 1):  # next units' all-gathers overlap this unit's math
-                if self._index + k < len(order):
-                    order[self._index + k].unit.unshard()
-        self.unit.wait_unshard()
+        (self._root or self)._runtime.pre_forward(self._index)
         return None
 
     def _post_forward(self, module, args, output):
-        root = self._root or self
-        if torch.is_grad_enabled():
-            self._register_pre_backward(output)
-        in_bwd = root._runtime.in_backward()  # a recomputed forward inside backward must not reshard
-        if (self.sharding_strategy is ShardingStrategy.FULL_SHARD and self.unit.reshard_after_forward
-                and not in_bwd):
-            self.unit.reshard()
+        if torch.is_tensor(output):
+            outs = [output]
+        else:
+            outs = []
+            _collect_tensors(output, outs)
+        (self._root or self)._runtime.post_forward(self._index, outs)
         return None
-
-    def _register_pre_backward(self, output) -> None:
-        tensors = []
-
-        def collect(o):
-            if torch.is_tensor(o):
-                if o.requires_grad:
-                    tensors.append(o)
-            elif isinstance(o, (list, tuple)):
-                for x in o:
-                    collect(x)
-            elif isinstance(o, dict):
-                for x in o.values():
-                    collect(x)
-
-        collect(output)
-        fired = [False]
-
-        def hook(grad):
-            if not fired[0]:
-                fired[0] = True
-                self._pre_backward()
-            return grad
-
-        for t in tensors:
-            t.register_hook(hook)
-
-    def _pre_backward(self) -> None:
-        root = self._root or self
-        root._runtime.mark_pre_backward()
-        self.unit.unshard()
-        # Backward visits the units as root (LM head), last block, ..., first block, root
-        # (embeddings); the root never reshards in between, so the chain to prefetch is
-        # root -> n-1 -> n-2 -> ... -> 1.
-        order = root._order
-        j = self._index
-        for _ in range(self.backward_prefetch):
-            j = len(order) - 1 if j == 0 else j - 1
-            if j < 1:
-                break
-            order[j].unit.unshard()
-        self.unit.wait_unshard()
 
     # ------------------------------------------------------------------ module surface
     def forward(self, *args, **kwargs):
@@ -257,34 +206,26 @@ class FSDP(nn.Module):
                 u.unit.reshard()
 
     def state_dict(self, *args, rank0_only: bool = False, cpu_offload: bool = True, **kwargs):
-        """FULL state dict under the original parameter names. Collective: every rank must call
-        it (a rank-0-only call deadlocks, which is what the reference's
-        ``if rank == 0: save_checkpoint`` would do under sharding)."""
+        """FULL state dict under the original parameter names, values = the fp32 master weights
+        (gathered from the shards; the bf16 compute copy is never the source, so a checkpoint
+        round trip loses nothing). Collective: every rank must call it (a rank-0-only call
+        deadlocks, which is what the reference's ``if rank == 0: save_checkpoint`` would do
+        under sharding)."""
         if kwargs.get("destination") is not None or (args and args[0] is not None):
             # Called as a child while an enclosing module collects its state dict: behave like a
-            # plain container (the outermost call owns unsharding and the key clean-up).
+            # plain container (the outermost call owns the gathering and the key clean-up).
             return nn.Module.state_dict(self, *args, **kwargs)
-        with self.summon_full_params():
-            sd = self.module.state_dict(*args, **kwargs)
-            sd = {k.replace("module.", ""): v for k, v in sd.items()}
-            if rank0_only and self.rank != 0:
-                return {}
-            # Always a copy: the views die when the units reshard on leaving this block.
-            return {k: (v.detach().cpu() if (cpu_offload and v.is_cuda) else v.detach().clone())
-                    for k, v in sd.items()}
+        from .checkpoint import full_model_state_dict
+
+        return full_model_state_dict(self, cpu_offload=cpu_offload, rank0_only=rank0_only)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
-        """Loads a FULL state dict (every rank passes the same one) and re-shards."""
-        state_dict = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state_dict.items()}
-        with self.summon_full_params(writeback=True):
-            own = self.module.state_dict()
-            remap = {}
-            for k in own:
-                remap[k.replace("module.", "")] = k
-            fixed = {remap.get(k, k): v for k, v in state_dict.items()}
-            with torch.no_grad():
-                result = self.module.load_state_dict(fixed, strict=strict, **kwargs)
-        return result
+        """Loads a FULL state dict (every rank passes the same one): each unit's fp32 master
+        shard is cut straight out of it."""
+        from .checkpoint import load_full_model_state_dict
+
+        missing, unexpected = load_full_model_state_dict(self, state_dict, strict=strict)
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def full_optim_state_dict(self, optimizer, cpu_offload: bool = True):
         """Optimizer state in torch.optim.AdamW layout over the bare model's parameters (collective)."""
@@ -302,6 +243,17 @@ class FSDP(nn.Module):
             return super().__getattr__(name)
         except AttributeError:
             return getattr(super().__getattr__("module"), name)
+
+
+def _collect_tensors(o, out: list) -> None:
+    if torch.is_tensor(o):
+        out.append(o)
+    elif isinstance(o, (list, tuple)):
+        for x in o:
+            _collect_tensors(x, out)
+    elif isinstance(o, dict):
+        for x in o.values():
+            _collect_tensors(x, out)
 
 
 def fsdp_wrap_gpt(model: nn.Module, sharding_strategy=ShardingStrategy.FULL_SHARD, unit_blocks: int = 1,

@@ -19,9 +19,9 @@ import os
 from typing import Any, Optional
 
 import torch
-import torch.distributed as dist
 import torch.nn as nn
 
+from ..parallel import comm
 from .trainer import Trainer
 
 
@@ -37,15 +37,15 @@ class DistributedTrainer(Trainer):
                          checkpoint_dir=checkpoint_dir, metrics_file=metrics_file)
         self.ddp_enabled = ddp_enabled
         if ddp_enabled:
-            if not dist.is_initialized():
-                raise RuntimeError("torch.distributed is not initialized. Call "
-                                   "pytorch_distributed_amd.parallel.init_distributed() (or "
-                                   "torch.distributed.init_process_group) before creating DistributedTrainer.")
+            if not comm.is_initialized():
+                raise RuntimeError("No communicator is initialized. Call "
+                                   "pytorch_distributed_amd.parallel.init_distributed() before creating "
+                                   "DistributedTrainer.")
             if not hasattr(model, "no_sync"):
                 raise RuntimeError("Model does not have 'no_sync' method. Wrap it with DDP or FSDP before "
                                    "passing it to DistributedTrainer.")
-            self.rank = dist.get_rank()
-            self.world_size = dist.get_world_size()
+            self.rank = comm.get_rank()
+            self.world_size = comm.get_world_size()
         else:
             self.rank, self.world_size = 0, 1
 
@@ -75,9 +75,16 @@ class DistributedTrainer(Trainer):
         """Mean of the ranks' window losses. Every rank calls this on logging steps."""
         if not self.ddp_enabled or self.world_size == 1:
             return loss
-        t = torch.tensor([loss], dtype=torch.float32, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # SUM / W: the gloo backend has no AVG
-        return float(t.item()) / self.world_size
+        return comm.all_reduce_mean_scalar(loss, device)
+
+    def _window_loss(self, device) -> float:
+        """The logged loss: mean over the accumulation window and over ranks. The 4-byte all-reduce
+        is issued on the communicator's reduction stream straight from the device-side
+        accumulator; the host blocks once, on the result."""
+        if not self.ddp_enabled or self.world_size == 1:
+            return super()._window_loss(device)
+        lazy = comm.LazyScalarMean(self.loss_accumulator / self.grad_accumulation_steps)
+        return lazy.value()
 
     # Checkpoints: state is gathered by all ranks (collective for sharded models); the base
     # class lets only rank 0 write the file.
@@ -100,4 +107,4 @@ class DistributedTrainer(Trainer):
     def save_checkpoint(self, path) -> None:
         super().save_checkpoint(path)
         if self.ddp_enabled and self.world_size > 1:
-            dist.barrier()
+            comm.barrier()

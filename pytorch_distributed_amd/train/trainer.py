@@ -71,6 +71,8 @@ class Trainer:
         self.start_time = None
         self._tokens_since_log = 0
         self._time_of_last_log = None
+        self._dataloader = None
+        self._resume_data_state = None  # stream position from a loaded checkpoint, applied by train()
 
         if save_every_n_steps is not None:
             os.makedirs(checkpoint_dir, exist_ok=True)
@@ -158,10 +160,20 @@ class Trainer:
     def _aggregate_loss(self, loss: float, device) -> float:
         return loss
 
+    def _window_loss(self, device) -> float:
+        """Mean loss of the accumulation window (the only host synchronisation of a logging step)."""
+        avg = float(self.loss_accumulator.item()) / self.grad_accumulation_steps
+        return self._aggregate_loss(avg, device)
+
     def _maybe_checkpoint(self) -> None:
-        if (self.save_every_n_steps is not None and self.current_step > 0
-                and self.current_step % self.save_every_n_steps == 0):
-            path = f"{self.checkpoint_dir}/checkpoint_step_{self.current_step}.pt"
+        """Called after step index ``current_step - 1`` has completed. File names and the trigger
+        follow the reference (``checkpoint_step_{index}.pt`` when ``index > 0 and index % n == 0``,
+        trainer.py:100-106). The stored ``step`` is the number of completed optimizer steps, i.e.
+        the index the resumed run continues with; the reference stores the index it has just
+        finished, so a run resumed there repeats that index once."""
+        done = self.current_step - 1
+        if self.save_every_n_steps is not None and done > 0 and done % self.save_every_n_steps == 0:
+            path = f"{self.checkpoint_dir}/checkpoint_step_{done}.pt"
             self.save_checkpoint(path)
             if self.rank == 0:
                 print(f"Saved: {path}")
@@ -181,7 +193,9 @@ class Trainer:
             raise ValueError("gradient accumulation steps must be >= 1 "
                              "(global batch smaller than micro batch x world size?)")
 
-        for inputs, targets in dataloader:
+        self._dataloader = dataloader
+        batches = self._resume_data(dataloader)
+        for inputs, targets in batches:
             if self.current_step >= self.max_steps:
                 break
             device = inputs.device
@@ -198,11 +212,10 @@ class Trainer:
             if is_last_microbatch:
                 self._optimizer_step()
                 if self.current_step % self.log_every_n_steps == 0:
-                    avg = float(self.loss_accumulator.item()) / self.grad_accumulation_steps  # only host sync
-                    self._log(self._aggregate_loss(avg, device), device)
-                self._maybe_checkpoint()
+                    self._log(self._window_loss(device), device)
                 self.loss_accumulator.zero_()
                 self.current_step += 1
+                self._maybe_checkpoint()
 
             if profiler is not None:
                 profiler.step()
@@ -214,6 +227,31 @@ class Trainer:
 
     def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:
         return self.training_step(inputs, targets)
+
+    # ------------------------------------------------------------------ data position
+    def _data_state(self) -> dict:
+        """Where the token stream stands: micro-batches consumed (and the loader's own state when it
+        has one). The reference's checkpoint has no such entry, so a resumed run there re-reads the
+        data from the first shard."""
+        state = {"batch_count": self.batch_count}
+        loader_state = getattr(self._dataloader, "state_dict", None)
+        if loader_state is not None:
+            state["loader"] = loader_state()
+        return state
+
+    def _resume_data(self, dataloader):
+        """The iterator ``train`` consumes: positioned after the batches a loaded checkpoint had seen."""
+        state, self._resume_data_state = self._resume_data_state, None
+        if not state:
+            return iter(dataloader)
+        done = int(state.get("batch_count", 0))
+        if hasattr(dataloader, "load_state_dict"):
+            dataloader.load_state_dict(state.get("loader") or {"batches": done})
+            return iter(dataloader)
+        it = iter(dataloader)  # a loader without a position of its own: read past what was consumed
+        for _ in range(done):
+            next(it, None)
+        return it
 
     # ------------------------------------------------------------------ checkpoints
     def _model_state_dict(self):
@@ -227,6 +265,7 @@ class Trainer:
             "model_state_dict": self._model_state_dict(),
             "optimizer_state_dict": self._optimizer_state_dict(),
             "step": self.current_step,
+            "data_state": self._data_state(),
         }
         if self.lr_scheduler is not None:
             checkpoint["lr_scheduler_state_dict"] = self.lr_scheduler.state_dict()
@@ -243,6 +282,10 @@ class Trainer:
         self._load_model_state(state)
         self._load_optimizer_state(checkpoint["optimizer_state_dict"])
         self.current_step = checkpoint.get("step", 0)
+        data_state = checkpoint.get("data_state")  # absent in checkpoints written by the reference trainer
+        if data_state:
+            self.batch_count = int(data_state.get("batch_count", 0))
+            self._resume_data_state = data_state
         if self.lr_scheduler is not None and "lr_scheduler_state_dict" in checkpoint:
             self.lr_scheduler.load_state_dict(checkpoint["lr_scheduler_state_dict"])
         if self.rank == 0:

@@ -1,4 +1,5 @@
-"""Helpers for multi-process CPU (gloo) tests."""
+"""Helpers for multi-process CPU tests (the native socket communicator; backend="c10d" runs the
+same test over a torch.distributed gloo group through the adapter)."""
 import os
 import socket
 import sys
@@ -17,7 +18,7 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def _entry(rank, world, port, fn, args, err_dir):
+def _entry(rank, world, port, fn, args, err_dir, backend="socket"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     if ROOT not in sys.path:
@@ -26,7 +27,7 @@ def _entry(rank, world, port, fn, args, err_dir):
     try:
         from pytorch_distributed_amd.parallel import init_distributed, shutdown
 
-        init_distributed(backend="gloo", timeout_s=120)
+        init_distributed(backend=backend, timeout_s=120)
         fn(rank, world, *args)
         shutdown()
     except BaseException:  # noqa: BLE001 - the parent reports the traceback
@@ -35,12 +36,12 @@ def _entry(rank, world, port, fn, args, err_dir):
         os._exit(1)  # do not wait in atexit handlers for peers that are stuck in a collective
 
 
-def run_distributed(fn, world: int = 2, args=(), timeout: float = 240.0):
-    """Runs ``fn(rank, world, *args)`` in ``world`` gloo processes; raises on any failure."""
+def run_distributed(fn, world: int = 2, args=(), timeout: float = 240.0, backend: str = "socket"):
+    """Runs ``fn(rank, world, *args)`` in ``world`` CPU processes; raises on any failure."""
     ctx = mp.get_context("spawn")
     port = free_port()
     with tempfile.TemporaryDirectory() as err_dir:
-        procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, err_dir)) for r in range(world)]
+        procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, err_dir, backend)) for r in range(world)]
         for p in procs:
             p.start()
         import time

@@ -240,11 +240,13 @@ def test_trainer_log_format_accumulation_and_checkpoint(tmp_path, capsys):
     assert tr.current_step == 4 and tr.batch_count == 8
     path = tmp_path / "ckpt" / "checkpoint_step_2.pt"
     ck = torch.load(path, weights_only=True)
-    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "step", "lr_scheduler_state_dict"}
-    assert ck["step"] == 2
+    # the reference's four keys plus the position of the token stream
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "step", "lr_scheduler_state_dict", "data_state"}
+    assert ck["step"] == 3  # optimizer steps completed when step index 2 had finished
+    assert ck["data_state"]["batch_count"] == 6 and ck["data_state"]["loader"] == {"batches": 6}
     tr2, _ = _trainer(tmp_path, seed=1)
     tr2.load_checkpoint(path)
-    assert tr2.current_step == 2
+    assert tr2.current_step == 3 and tr2.batch_count == 6
     for k, v in tr2.model.state_dict().items():
         assert torch.equal(v, ck["model_state_dict"][k])
     # checkpoints written by a DDP-wrapped torch model carry a "module." prefix: accepted

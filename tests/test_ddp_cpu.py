@@ -1,4 +1,4 @@
-"""DDP on the native reducer, two gloo processes on the CPU."""
+"""DDP on the native reducer, CPU processes on the native socket communicator."""
 import copy
 
 import pytest
@@ -148,8 +148,7 @@ def _reduce_fp32(rank, world, kind):
     """bf16 model, gradients reduced through an fp32 copy: the averaged gradient must equal the
     fp32 mean of the two ranks' bf16 gradients rounded ONCE (a bf16 reduction rounds the sum too),
     and the fp32-reduced run must agree with the default one to bf16 accuracy."""
-    import torch.distributed as dist
-    from pytorch_distributed_amd.parallel import DDP, FSDP, ShardingStrategy
+    from pytorch_distributed_amd.parallel import DDP, FSDP, ShardingStrategy, all_reduce
 
     def grads(reduce_fp32):
         model = _tiny_model(0).to(torch.bfloat16)
@@ -174,7 +173,7 @@ def _reduce_fp32(rank, world, kind):
         local(x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]).backward()
         mine = torch.cat([p.grad.detach().float().reshape(-1) for p in local.parameters()])
         total = mine.clone()
-        dist.all_reduce(total)
+        all_reduce(total)
         expect = (total / world).to(torch.bfloat16).float()
         assert torch.equal(wide, expect)
 

@@ -5,7 +5,6 @@ import os
 
 import pytest
 import torch
-import torch.distributed as dist
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -20,7 +19,7 @@ def pg():
     os.environ.setdefault("LOCAL_RANK", "0")
     from pytorch_distributed_amd.parallel import init_distributed, shutdown
 
-    init_distributed(backend="nccl")
+    init_distributed(backend="rccl")
     yield
     shutdown()
 

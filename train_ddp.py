@@ -3,31 +3,35 @@
 The reference's ``train_ddp.py`` run (assignments/assignment1/train_ddp.py:54-146: same
 hyper-parameters as the baseline, global batch 32 split over the ranks, seed 42 on every
 rank, per-rank traces in ``outputs/traces/ddp/rank{r}_trace.json``) on this framework's DDP:
-a C++ bucket reducer launching RCCL all-reduces from autograd hooks. Runs on CPUs too
-(gloo). With 8 GPUs pass ``--global-batch-size 64`` (32 is smaller than 8 x 8).
+a C++ bucket reducer launching reductions on the framework's own RCCL communicator from autograd
+hooks. Runs on CPUs too (``--backend socket``). With 8 GPUs pass ``--global-batch-size 64`` (32 is
+smaller than 8 x 8). Bucket size and reduction algorithm come from a start-up measurement of the
+fabric unless given (``--bucket-mb``, ``--ddp-decompose``).
 """
 import argparse
 import os
 
 import torch
 
-from pytorch_distributed_amd.parallel import DDP, init_distributed, shutdown
+from pytorch_distributed_amd.parallel import DDP, autotune, init_distributed, plan_sync, shutdown
 from pytorch_distributed_amd.train import DistributedTrainer
 from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
-def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False):
-    """``model`` (already on ``device``) wrapped in DDP."""
-    kw = {} if bucket_cap_mb is None else {"bucket_cap_mb": bucket_cap_mb}
+def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False, decompose=None):
+    """``model`` (already on ``device``) wrapped in DDP (None = the start-up measurement's choice)."""
     ids = [device.index] if device.type == "cuda" else None
-    return DDP(model, device_ids=ids, reduce_fp32=reduce_fp32, **kw)
+    return DDP(model, device_ids=ids, reduce_fp32=reduce_fp32, bucket_cap_mb=bucket_cap_mb, decompose=decompose)
 
 
 def main():
     ap = cli.add_common_args(argparse.ArgumentParser(description=__doc__))
-    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size (default 64 MiB)")
-    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"])
+    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size (default: measured)")
+    ap.add_argument("--ddp-decompose", choices=["auto", "on", "off"], default="auto",
+                    help="reduce buckets as reduce-scatter + all-gather instead of all-reduce (auto: measured)")
+    ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
+    ap.add_argument("--backend", default=None, choices=[None, "rccl", "socket", "c10d", "nccl", "gloo"])
     ap.add_argument("--reduce-fp32", action="store_true", help="all-reduce bf16 gradients through an fp32 copy")
     args = ap.parse_args()
     rank, world, device = init_distributed(args.backend)
@@ -36,10 +40,16 @@ def main():
         print(f"\nDDP Configuration:\nGlobal batch size: {args.global_batch_size}\n"
               f"Micro batch size per rank: {args.micro_batch_size}\nWorld size: {world}\n"
               f"Sequence length: {args.sequence_length}\nMax steps: {args.max_steps}")
+    if world > 1 and not args.no_comm_autotune:
+        autotune.tune(device=device)
     model, cfg = cli.build_model(args, device, dtype)  # same seed on every rank
-    model = setup_ddp_model(model, device, args.bucket_mb, args.reduce_fp32)
+    if device.type == "cuda" and dtype == torch.bfloat16:
+        plan_sync.plan_gemms(model, args.micro_batch_size, args.sequence_length, cfg.vocab_size)
+    model = setup_ddp_model(model, device, args.bucket_mb, args.reduce_fp32,
+                            {"auto": None, "on": True, "off": False}[args.ddp_decompose])
     if rank == 0:
-        print(f"Model wrapped with DDP ({model.reducer.num_buckets} gradient buckets)")
+        print(f"Model wrapped with DDP ({model.reducer.num_buckets} gradient buckets of <= {model.bucket_cap_mb:g} MiB"
+              f"{', reduce-scatter + all-gather' if model.decompose else ''})")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
     optimizer, scheduler = cli.build_optimizer(args, model.parameters())
     trainer = DistributedTrainer(model, optimizer, scheduler, max_steps=args.max_steps,

@@ -4,14 +4,17 @@
 The reference's ``train_fsdp.py`` run (assignments/assignment1/train_fsdp.py:86-190: every
 ``transformer.h[i]`` wrapped on its own, then the root; same trainer and hyper-parameters as
 DDP; traces in ``outputs/traces/fsdp_{strategy}/rank{r}_trace.json``) on this framework's
-flat-parameter runtime. ``--fsdp-unit-blocks k`` groups k blocks per communication unit.
+flat-parameter runtime. ``--fsdp-unit-blocks k`` groups k blocks per communication unit; without the
+flag the unit size follows a start-up measurement of the all-gather curve (one block per unit, the
+reference's wrapping, on a single rank or with ``--no-comm-autotune``).
 """
 import argparse
 import os
 
 import torch
 
-from pytorch_distributed_amd.parallel import FSDP, ShardingStrategy, fsdp_wrap_gpt, init_distributed, shutdown
+from pytorch_distributed_amd.parallel import (FSDP, ShardingStrategy, autotune, fsdp_wrap_gpt, init_distributed,
+                                              plan_sync, shutdown)
 from pytorch_distributed_amd.train import DistributedTrainer
 from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
@@ -32,9 +35,11 @@ def main():
     ap = cli.add_common_args(argparse.ArgumentParser(description=__doc__))
     ap.add_argument("--strategy", type=str, default="FULL_SHARD",
                     choices=["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"], help="FSDP sharding strategy")
-    ap.add_argument("--fsdp-unit-blocks", type=int, default=1)
+    ap.add_argument("--fsdp-unit-blocks", type=int, default=None,
+                    help="transformer blocks per sharding unit (default: from the start-up measurement)")
+    ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
     ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
-    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"])
+    ap.add_argument("--backend", default=None, choices=[None, "rccl", "socket", "c10d", "nccl", "gloo"])
     ap.add_argument("--sharded-checkpoint", default=None,
                     help="directory: also write a per-rank sharded checkpoint at the end of training")
     args = ap.parse_args()
@@ -44,10 +49,18 @@ def main():
         print(f"\nFSDP Configuration:\nSharding strategy: {args.strategy}\n"
               f"Global batch size: {args.global_batch_size}\nMicro batch size per rank: {args.micro_batch_size}\n"
               f"World size: {world}\nSequence length: {args.sequence_length}\nMax steps: {args.max_steps}")
+    policy = autotune.tune(device=device) if world > 1 and not args.no_comm_autotune else None
     model, cfg = cli.build_model(args, device, dtype)
-    model = setup_fsdp_model(model, device, args.strategy, args.fsdp_unit_blocks, args.reduce_fp32)
+    if device.type == "cuda" and dtype == torch.bfloat16:
+        plan_sync.plan_gemms(model, args.micro_batch_size, args.sequence_length, cfg.vocab_size)
+    unit_blocks = args.fsdp_unit_blocks
+    if unit_blocks is None:
+        blocks = model.transformer.h
+        block_bytes = sum(p.numel() * p.element_size() for p in blocks[0].parameters())
+        unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
+    model = setup_fsdp_model(model, device, args.strategy, unit_blocks, args.reduce_fp32)
     if rank == 0:
-        print(f"Model wrapped with FSDP ({args.strategy})")
+        print(f"Model wrapped with FSDP ({args.strategy}, {unit_blocks} block(s) per unit)")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
     optimizer, scheduler = cli.build_optimizer(args, model.parameters())
     trainer = DistributedTrainer(model, optimizer, scheduler, max_steps=args.max_steps,
