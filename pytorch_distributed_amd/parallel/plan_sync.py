@@ -21,9 +21,12 @@ from typing import Optional
 
 import torch
 
+import importlib
+
 from .. import _ext
-from ..ops import linear as _linear
 from . import comm
+
+_linear = importlib.import_module("pytorch_distributed_amd.ops.linear")  # the module (ops.linear is also a function)
 
 
 def export_decisions() -> dict:
