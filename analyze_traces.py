@@ -4,6 +4,11 @@ rank, and kernel-level diffs Baseline->DDP, DDP->FSDP_FULL, DDP->FSDP_GRAD, FULL
 rank 0 inside one profiler step (``--step``, default 4 like the notebook's "iteration 4").
 
 usage: python analyze_traces.py [--traces outputs/traces] [--step 4]
+       python analyze_traces.py --from-rocprof <rocprofv3 output dir> --config ddp    (build the traces first)
+
+``--from-rocprof`` converts a ``rocprofv3 --kernel-trace --marker-trace`` run of a train script into
+``<traces>/<config>/rank{r}_trace.json`` (kernel rows per HIP stream, collectives on their own row,
+the framework's named ranges) and then analyses as usual: no Kineto involved.
 """
 import argparse
 import os
@@ -26,7 +31,18 @@ def main():
     ap.add_argument("--traces", default="outputs/traces")
     ap.add_argument("--step", type=int, default=4)
     ap.add_argument("--top", type=int, default=15)
+    ap.add_argument("--from-rocprof", default=None, help="rocprofv3 output directory to convert first")
+    ap.add_argument("--config", default="baseline", help="configuration name the converted traces are filed under")
+    ap.add_argument("--active-only", action="store_true", help="keep only what ran inside the ProfilerStep windows")
     args = ap.parse_args()
+    if args.from_rocprof:
+        from pytorch_distributed_amd.utils import rocprof_trace
+
+        written = rocprof_trace.merge(args.from_rocprof, os.path.join(args.traces, args.config), args.active_only)
+        for rank, path in sorted(written.items()):
+            print(f"wrote {path}")
+        if args.config == "baseline" and 0 in written:  # the reference's baseline trace is a single trace.json
+            os.replace(written[0], os.path.join(args.traces, args.config, "trace.json"))
 
     print(f"{'config':<22}{'rank':>5}{'compute%':>10}{'non-comp%':>11}{'idle%':>8}{'comm ms':>10}{'overlap%':>10}")
     loaded = {}

@@ -2,6 +2,8 @@
 #include "communicator.h"
 #include "store.h"
 
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
@@ -117,6 +119,48 @@ void bind_comm(py::module_& m) {
       },
       py::arg("kind"), py::arg("rank"), py::arg("world_size"), py::arg("host"), py::arg("port"), py::arg("device") = 0,
       py::arg("timeout_s") = 600.0, py::arg("job_id") = "", py::call_guard<py::gil_scoped_release>());
+  // Diagnosis: the communicator's fence pattern (current stream -> side stream -> current stream)
+  // n times without a host synchronisation, with a chosen event life cycle:
+  //   0 = fresh events, all kept until the end      1 = fresh events, destroyed right after use
+  //   2 = ONE event re-recorded for every fence      3 = two events (ready / done) re-recorded
+  m.def(
+      "debug_fence_chain",
+      [](int64_t side_handle, int n, int mode) {
+        hipStream_t side = reinterpret_cast<hipStream_t>((uintptr_t)side_handle);
+        hipStream_t cur = c10::hip::getCurrentHIPStream().stream();
+        std::vector<hipEvent_t> keep;
+        hipEvent_t fixed[2] = {nullptr, nullptr};
+        auto make = [&](int which) {
+          hipEvent_t e = nullptr;
+          if (mode == 2 || mode == 3) {
+            const int slot = mode == 2 ? 0 : which;
+            if (!fixed[slot]) TORCH_CHECK(hipEventCreateWithFlags(&fixed[slot], hipEventDisableTiming) == hipSuccess);
+            return fixed[slot];
+          }
+          TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess);
+          if (mode == 0) keep.push_back(e);
+          return e;
+        };
+        auto drop = [&](hipEvent_t e) {
+          if (mode == 1) (void)hipEventDestroy(e);
+        };
+        for (int i = 0; i < n; ++i) {
+          hipEvent_t ready = make(0);
+          TORCH_CHECK(hipEventRecord(ready, cur) == hipSuccess);
+          TORCH_CHECK(hipStreamWaitEvent(side, ready, 0) == hipSuccess);
+          drop(ready);
+          hipEvent_t done = make(1);
+          TORCH_CHECK(hipEventRecord(done, side) == hipSuccess);
+          TORCH_CHECK(hipStreamWaitEvent(cur, done, 0) == hipSuccess);
+          drop(done);
+        }
+        TORCH_CHECK(hipStreamSynchronize(cur) == hipSuccess);
+        for (hipEvent_t e : keep) (void)hipEventDestroy(e);
+        for (hipEvent_t e : fixed)
+          if (e) (void)hipEventDestroy(e);
+        return (int64_t)(uintptr_t)cur;
+      },
+      py::arg("side_stream"), py::arg("n"), py::arg("mode"), py::call_guard<py::gil_scoped_release>());
   m.def("wrap_process_group", &make_c10d_communicator, py::arg("process_group"));
   m.def("recording_communicator", &make_recording_communicator, py::arg("inner"));
 }

@@ -1,9 +1,9 @@
 // RCCL communicator: the GPU implementation of pda::comm::Communicator (see communicator.h).
 //
-// Streams. The communicator owns two high-priority HIP streams, one per Queue. Together with
-// the caller's compute stream that is three of the four hardware queues a process gets, so
-// collectives never share a hardware queue with compute kernels and an all-gather for the
-// next unit is never stuck behind a reduce-scatter of the previous one.
+// Streams. The communicator owns two HIP streams, one per Queue. Together with the caller's
+// compute stream that is three of the four hardware queues a process gets, so collectives never
+// share a hardware queue with compute kernels and an all-gather for the next unit is never
+// stuck behind a reduce-scatter of the previous one.
 //
 // Fences. issue(): an event recorded on the caller's stream is awaited by the queue's stream
 // (the collective sees every kernel enqueued before it), the RCCL call is enqueued, and a
@@ -25,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <thread>
@@ -157,14 +158,29 @@ class RcclCommunicator final : public Communicator {
       TORCH_CHECK(bytes.size() == sizeof(id), "communicator: malformed RCCL unique id in the store");
       std::memcpy(&id, bytes.data(), sizeof(id));
     }
+    // The streams are created BEFORE the library initialises, at normal priority. Measured on this
+    // stack (ROCm 7.0 runtime, RCCL 2.26): the first high-priority stream created after
+    // ncclCommInitRank stops draining as soon as it exchanges more than a couple of event fences with
+    // the default stream (tools/micro/comm_chain.py reproduces it; streams created before the
+    // initialisation, or at normal priority, do not show it). PDA_COMM_STREAM_PRIORITY=high opts into
+    // high-priority streams (still created first).
+    {
+      const char* pr = std::getenv("PDA_COMM_STREAM_PRIORITY");
+      const bool high = pr != nullptr && pr[0] == 'h';
+      int least = 0, greatest = 0;
+      PDA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      for (int q = 0; q < 2; ++q) {
+        if (high) PDA_HIP(hipStreamCreateWithPriority(&streams_[q], hipStreamNonBlocking, greatest));
+        else PDA_HIP(hipStreamCreateWithFlags(&streams_[q], hipStreamNonBlocking));
+      }
+    }
     PDA_NCCL(ncclCommInitRank(&comm_, world_, id, rank_));
-    int lo = 0, hi = 0;
-    PDA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi = numerically lowest = highest priority
-    for (int q = 0; q < 2; ++q) PDA_HIP(hipStreamCreateWithPriority(&streams_[q], hipStreamNonBlocking, hi));
     int version = 0;
     (void)ncclGetVersion(&version);
     version_ = version;
-    watchdog_ = std::thread([this] { watch(); });
+    const char* wd = std::getenv("PDA_COMM_WATCHDOG");
+    use_watchdog_ = !(wd != nullptr && wd[0] == '0');
+    if (use_watchdog_) watchdog_ = std::thread([this] { watch(); });
   }
 
   ~RcclCommunicator() override {
@@ -267,7 +283,7 @@ class RcclCommunicator final : public Communicator {
     auto done = std::make_shared<PooledEvent>(pool_);
     PDA_HIP(hipEventRecord(done->event, s));
     if (prev != device_) PDA_HIP(hipSetDevice(prev));
-    {
+    if (use_watchdog_) {
       std::lock_guard<std::mutex> wl(watch_mu_);
       watched_.push_back({done, now_s(), what});
     }
@@ -323,6 +339,7 @@ class RcclCommunicator final : public Communicator {
   std::condition_variable watch_cv_;
   std::deque<Watched> watched_;
   bool stop_ = false;
+  bool use_watchdog_ = true;
 };
 
 }  // namespace

@@ -40,6 +40,7 @@
 
 #include "comm/communicator.h"
 #include "comm_debug.h"
+#include "range_tracer.h"
 
 #include <memory>
 #include <mutex>
@@ -180,6 +181,7 @@ class ShardedUnit {
     if (strategy_ == kNoShard || unsharded_) return;
     if (!ag_issued_) unshard();
     if (ag_work_) {
+      pda::trace::Scope range("all_gather wait", "comm");  // on the GPU clock: the exposed part of the all-gather
       ag_work_->wait();
       ag_work_.reset();
     }
@@ -320,6 +322,7 @@ class ShardedUnit {
   void launch_reduce() {
     reduce_launched_ = true;
     if (!grad_allocated_) return;
+    pda::trace::Scope range(strategy_ == kNoShard ? "all_reduce launch" : "reduce_scatter launch", "comm");
     zero_unwritten();
     // fp32 reduction of low-precision gradients: the collective runs on a widened copy (twice
     // the bytes on the wire, no rounding between the ranks' contributions); with an fp32 master
@@ -513,6 +516,7 @@ class ShardedRuntime {
   void finish_pass() {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     if (!in_pass_) return;
+    pda::trace::Scope range("gradient reduction wait (end of backward)", "comm");
     if (require_sync_) {
       // Units whose parameters did not all receive a gradient: reduce what there is, in
       // unit order (identical on every rank).

@@ -7,19 +7,32 @@
 // roctxRangePush / roctxRangePop when libroctx64 is loadable, so a rocprofv3 marker trace
 // of the same run carries identical annotations next to the kernel rows.
 //
-// This is the light-weight, always-available half of the profiling story (the reference
-// wraps training in torch.profiler: assignments/assignment1/train_baseline.py:79-87);
-// kernel-level traces come from rocprofv3 / the Kineto backend of utils.profiler.
+// Ranges come from two places: Python (`StepProfiler.range`, the trainers' forward / backward /
+// optimizer phases) and the C++ runtime itself (all-gather wait, reduce-scatter launch,
+// end-of-backward fence in reducer.cpp / fsdp_unit.cpp) through pda::trace::Scope, which
+// records into whichever tracer is currently ACTIVE (RangeTracer.activate()) and costs one
+// atomic load when none is. Ranges may be opened on any thread (the autograd engine runs the
+// runtime's hooks on its own thread); every thread gets its own row.
+//
+// This is the framework's own tracer (the reference wraps training in torch.profiler:
+// assignments/assignment1/train_baseline.py:79-87). Kernel rows come from a rocprofv3
+// kernel trace of the same run; the roctx mirror puts both on one clock and
+// utils/rocprof_trace.py merges them into the per-rank Chrome trace.
+#include "range_tracer.h"
+
 #include <c10/hip/HIPStream.h>
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <torch/extension.h>
 
+#include <atomic>
 #include <chrono>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace py = pybind11;
@@ -54,6 +67,7 @@ struct Range {
   double host_begin = 0, host_end = 0;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   int depth = 0;
+  int thread = 0;  // 0 = the thread that created the tracer, 1.. = others in order of appearance
 };
 
 std::string json_escape(const std::string& s) {
@@ -79,10 +93,16 @@ class RangeTracer {
   }
 
   ~RangeTracer() {
+    deactivate();
     for (auto& r : done_) destroy(r);
-    for (auto& r : open_) destroy(r);
+    for (auto& kv : open_)
+      for (auto& r : kv.second) destroy(r);
     if (base_event_) hipEventDestroy(base_event_);
   }
+
+  // Makes this tracer the one the C++ runtime's pda::trace::Scope ranges go to.
+  void activate();
+  void deactivate();
 
   void set_enabled(bool e) { enabled_ = e; }
   bool enabled() const { return enabled_; }
@@ -90,24 +110,27 @@ class RangeTracer {
   void push(const std::string& name, const std::string& cat) {
     if (roctx().push) roctx().push(name.c_str());
     std::lock_guard<std::mutex> lk(mu_);
+    auto& stack = open_[std::this_thread::get_id()];
     Range r;
     r.name = name;
     r.cat = cat;
-    r.depth = (int)open_.size();
+    r.depth = (int)stack.size();
+    r.thread = thread_row();
     r.host_begin = now_us();
     if (enabled_ && use_gpu_) {
       hipEventCreate(&r.ev_begin);
       hipEventRecord(r.ev_begin, c10::hip::getCurrentHIPStream().stream());
     }
-    open_.push_back(std::move(r));
+    stack.push_back(std::move(r));
   }
 
   void pop() {
     if (roctx().pop) roctx().pop();
     std::lock_guard<std::mutex> lk(mu_);
-    TORCH_CHECK(!open_.empty(), "RangeTracer.pop without a matching push");
-    Range r = std::move(open_.back());
-    open_.pop_back();
+    auto& stack = open_[std::this_thread::get_id()];
+    TORCH_CHECK(!stack.empty(), "RangeTracer.pop without a matching push on this thread");
+    Range r = std::move(stack.back());
+    stack.pop_back();
     r.host_end = now_us();
     if (r.ev_begin) {
       hipEventCreate(&r.ev_end);
@@ -117,6 +140,17 @@ class RangeTracer {
     else destroy(r);
   }
 
+  // For pda::trace::Scope: closes the innermost range of this thread if there is one (a Scope that
+  // began while the tracer was disabled pushed nothing).
+  void pop_if_open() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = open_.find(std::this_thread::get_id());
+      if (it == open_.end() || it->second.empty()) return;
+    }
+    pop();
+  }
+
   void instant(const std::string& name) {
     std::lock_guard<std::mutex> lk(mu_);
     if (enabled_) instants_.emplace_back(name, now_us());
@@ -124,7 +158,8 @@ class RangeTracer {
 
   int64_t num_ranges() const { return (int64_t)done_.size(); }
 
-  // Chrome trace: pid = rank; tid 0 = host ranges, tid 1 = the same ranges on the GPU clock.
+  // Chrome trace: pid = rank; tid 0 = host ranges of the main thread, tid 1 = all ranges on the GPU
+  // clock (stream order), tid 2.. = host ranges of other threads (the autograd engine's).
   std::string to_json(int64_t rank) {
     std::lock_guard<std::mutex> lk(mu_);
     std::ostringstream o;
@@ -133,10 +168,13 @@ class RangeTracer {
     o << "{\"schemaVersion\":1,\"distributedInfo\":{\"rank\":" << rank << "},\"traceEvents\":[\n";
     o << "{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":0,\"name\":\"thread_name\",\"args\":{\"name\":\"host ranges\"}},\n";
     o << "{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":1,\"name\":\"thread_name\",\"args\":{\"name\":\"gpu ranges (stream order)\"}}";
+    for (int t = 1; t < next_thread_row_; ++t)
+      o << ",\n{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":" << (t + 1)
+        << ",\"name\":\"thread_name\",\"args\":{\"name\":\"host ranges (runtime thread " << t << ")\"}}";
     for (auto& r : done_) {
       o << ",\n{\"ph\":\"X\",\"cat\":\"" << json_escape(r.cat) << "\",\"name\":\"" << json_escape(r.name)
-        << "\",\"pid\":" << rank << ",\"tid\":0,\"ts\":" << (r.host_begin - base_host_)
-        << ",\"dur\":" << (r.host_end - r.host_begin) << "}";
+        << "\",\"pid\":" << rank << ",\"tid\":" << (r.thread == 0 ? 0 : r.thread + 1) << ",\"ts\":"
+        << (r.host_begin - base_host_) << ",\"dur\":" << (r.host_end - r.host_begin) << "}";
       if (r.ev_begin && r.ev_end) {
         hipEventSynchronize(r.ev_end);
         float b_ms = 0.f, d_ms = 0.f;
@@ -176,20 +214,58 @@ class RangeTracer {
     r.ev_begin = r.ev_end = nullptr;
   }
 
+  int thread_row() {  // called under mu_
+    const auto id = std::this_thread::get_id();
+    auto it = thread_rows_.find(id);
+    if (it == thread_rows_.end()) it = thread_rows_.emplace(id, next_thread_row_++).first;
+    return it->second;
+  }
+
+  std::map<std::thread::id, int> thread_rows_;
+  int next_thread_row_ = 0;
   bool use_gpu_;
   bool enabled_ = true;
   hipEvent_t base_event_ = nullptr;
   double base_host_ = 0;
-  std::vector<Range> open_, done_;
+  std::map<std::thread::id, std::vector<Range>> open_;
+  std::vector<Range> done_;
   std::vector<std::pair<std::string, double>> instants_;
   std::mutex mu_;
 };
 
+std::atomic<RangeTracer*> g_active{nullptr};
+
+void RangeTracer::activate() { g_active.store(this); }
+void RangeTracer::deactivate() {
+  RangeTracer* me = this;
+  g_active.compare_exchange_strong(me, nullptr);
+}
+
 }  // namespace
+
+namespace pda {
+namespace trace {
+
+bool active() { return g_active.load(std::memory_order_relaxed) != nullptr; }
+
+void push(const char* name, const char* cat) {
+  RangeTracer* t = g_active.load();
+  if (t != nullptr && t->enabled()) t->push(name, cat);
+}
+
+void pop() {
+  RangeTracer* t = g_active.load();
+  if (t != nullptr) t->pop_if_open();
+}
+
+}  // namespace trace
+}  // namespace pda
 
 void bind_tracer(py::module_& m) {
   py::class_<RangeTracer>(m, "RangeTracer")
       .def(py::init<bool>(), py::arg("use_gpu"))
+      .def("activate", &RangeTracer::activate)
+      .def("deactivate", &RangeTracer::deactivate)
       .def("push", &RangeTracer::push, py::arg("name"), py::arg("cat") = "range")
       .def("pop", &RangeTracer::pop)
       .def("instant", &RangeTracer::instant)

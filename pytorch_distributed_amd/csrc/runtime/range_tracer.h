@@ -1,0 +1,29 @@
+// Range annotations from inside the C++ runtime. A Scope records a named host + GPU range into
+// the currently active RangeTracer (range_tracer.cpp) and mirrors it to roctx; with no active
+// tracer it costs one atomic load.
+#pragma once
+
+namespace pda {
+namespace trace {
+
+bool active();
+void push(const char* name, const char* cat);
+void pop();
+
+class Scope {
+ public:
+  explicit Scope(const char* name, const char* cat = "runtime") : on_(active()) {
+    if (on_) push(name, cat);
+  }
+  ~Scope() {
+    if (on_) pop();
+  }
+  Scope(const Scope&) = delete;
+  Scope& operator=(const Scope&) = delete;
+
+ private:
+  bool on_;
+};
+
+}  // namespace trace
+}  // namespace pda

@@ -37,6 +37,7 @@
 
 #include "comm/communicator.h"
 #include "comm_debug.h"
+#include "range_tracer.h"
 
 #include <memory>
 #include <mutex>
@@ -261,6 +262,7 @@ class GradReducer {
   void launch(Bucket& b) {
     b.launched = true;
     if (!comm_ || (world_ == 1 && !force_collectives_)) return;
+    pda::trace::Scope range("bucket reduction launch", "comm");
     // fp32 reduction of low-precision gradients: the bucket is widened into a persistent fp32
     // twin, the twin is reduced (twice the bytes on the wire, no rounding between the ranks'
     // contributions) and narrowed back into the bucket when the pass finishes.
@@ -292,6 +294,7 @@ class GradReducer {
   void finish_pass() {
     std::lock_guard<std::mutex> lock(mu_);
     if (!in_pass_) return;
+    pda::trace::Scope range("gradient reduction wait (end of backward)", "comm");
     launch_ready_buckets(/*flush=*/true);
     for (auto& b : buckets_) {
       if (b.work.empty()) continue;

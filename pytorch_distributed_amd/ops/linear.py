@@ -18,8 +18,12 @@ weight gradient.
   GEMM of hundreds. ``input_grad_mm`` therefore times both routes the first time a shape is seen
   and keeps the faster one (``PDA_NO_DGRAD_TRANSPOSE=1`` pins the direct layout).
 
-Shapes the native paths do not cover (non-bf16, dimensions that are not multiples of 8, token
-counts that are not multiples of 32) and CPU tensors use ``torch`` matmuls.
+fp32 tensors on the GPU (``--dtype fp32``, the reference's storage precision) take the same path
+with bf16 MFMA inputs: activations, weight and bias are rounded to bf16 for the products,
+accumulation is fp32, results and gradients are widened back to fp32. Other GPU dtypes are an
+error; there is no eager fallback on the GPU. Shapes the native kernels do not cover (dimensions
+that are not multiples of 8, token counts that are not multiples of 32) fall to the library GEMM
+inside the same function, and CPU tensors use ``torch`` matmuls.
 ``PDA_NO_NATIVE_WGRAD=1`` / ``PDA_NO_GEMM_PLANNER=1`` switch the two native paths off
 (A/B measurements).
 """
@@ -179,6 +183,11 @@ class _LinearFn(torch.autograd.Function):
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     """``x @ weight.T + bias`` (``torch.nn.functional.linear`` semantics)."""
-    if _ext.use_hip(x) and x.dtype == torch.bfloat16:
-        return _LinearFn.apply(x, weight, bias)
+    if _ext.use_hip(x):
+        if x.dtype == torch.bfloat16:
+            return _LinearFn.apply(x, weight, bias)
+        if x.dtype == torch.float32:  # fp32 storage: bf16 MFMA inputs, fp32 accumulation, widened result
+            lo = torch.bfloat16
+            return _LinearFn.apply(x.to(lo), weight.to(lo), None if bias is None else bias.to(lo)).to(torch.float32)
+        raise NotImplementedError(f"linear on the GPU: dtype {x.dtype} has no kernel (bf16, or fp32 through bf16 MFMA inputs)")
     return F.linear(x, weight, bias)

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from ..parallel import comm
+from ..utils.profiler import annotate
 from .trainer import Trainer
 
 
@@ -61,11 +62,15 @@ class DistributedTrainer(Trainer):
         """Forward + backward; under ``model.no_sync()`` unless this micro-batch closes the window."""
         if self.ddp_enabled and not should_sync:
             with self.model.no_sync():
-                loss = self._loss(inputs, targets)
-                (loss / self.grad_accumulation_steps).backward()
+                with annotate("forward"):
+                    loss = self._loss(inputs, targets)
+                with annotate("backward (no_sync)"):
+                    (loss / self.grad_accumulation_steps).backward()
         else:
-            loss = self._loss(inputs, targets)
-            (loss / self.grad_accumulation_steps).backward()
+            with annotate("forward"):
+                loss = self._loss(inputs, targets)
+            with annotate("backward"):
+                (loss / self.grad_accumulation_steps).backward()
         return loss.detach()
 
     def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:

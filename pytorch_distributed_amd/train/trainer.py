@@ -33,6 +33,7 @@ import torch.nn as nn
 from .. import ops
 from ..optim import FusedAdamW
 from ..utils.flops import model_flops_per_token, mfu
+from ..utils.profiler import annotate
 
 
 def unwrap_model(model: nn.Module) -> nn.Module:
@@ -93,8 +94,10 @@ class Trainer:
 
     def training_step(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         """Forward + backward of one micro-batch; returns the (unscaled) loss, detached."""
-        loss = self._loss(inputs, targets)
-        (loss / self.grad_accumulation_steps).backward()
+        with annotate("forward"):
+            loss = self._loss(inputs, targets)
+        with annotate("backward"):
+            (loss / self.grad_accumulation_steps).backward()
         return loss.detach()
 
     # ------------------------------------------------------------------ helpers
@@ -104,11 +107,12 @@ class Trainer:
         self.loss_accumulator += loss.float()
 
     def _optimizer_step(self) -> None:
-        if isinstance(self.optimizer, FusedAdamW):
-            self.optimizer.step(zero_grad=True)
-        else:
-            self.optimizer.step()
-        self.optimizer.zero_grad()
+        with annotate("optimizer"):
+            if isinstance(self.optimizer, FusedAdamW):
+                self.optimizer.step(zero_grad=True)
+            else:
+                self.optimizer.step()
+            self.optimizer.zero_grad()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
 

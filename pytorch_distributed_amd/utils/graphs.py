@@ -17,7 +17,9 @@ What makes the step replayable:
 * inputs are copied into static buffers before each replay.
 
 Limits: single process (collectives of the data-parallel wrappers are not captured),
-fixed shapes, attention dropout off (its seed is drawn on the host).
+fixed shapes, every dropout off: the Philox seeds of attention dropout and of the residual /
+embedding dropout fused into the LayerNorm kernels are drawn on the host, so a capture would
+bake one seed in and every replay would repeat the same masks.
 """
 from __future__ import annotations
 
@@ -43,9 +45,14 @@ class GraphedTrainStep:
         self._loss = torch.zeros((), dtype=torch.float32, device=self.device)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._warmup_left = warmup_steps
-        for m in model.modules():
-            if getattr(m, "attn_pdrop", 0.0) and model.training:
-                raise ValueError("GraphedTrainStep: attention dropout draws its seed on the host; set it to 0")
+        if model.training:
+            for name, m in model.named_modules():
+                p = max(float(getattr(m, "attn_pdrop", 0.0) or 0.0), float(getattr(m, "out_pdrop", 0.0) or 0.0),
+                        float(m.p) if isinstance(m, torch.nn.Dropout) else 0.0)
+                if p > 0.0:
+                    raise ValueError(f"GraphedTrainStep: dropout (p={p} in '{name or type(m).__name__}') draws its "
+                                     "Philox seed on the host; a captured step would replay one mask for ever. "
+                                     "Set every dropout probability to 0 (config.without_dropout()).")
 
     def _eager_step(self) -> None:
         total = None

@@ -8,14 +8,18 @@ and a Chrome-trace JSON appears at ``trace_path`` when the active window closes.
 
 Backends:
 
-* ``"kineto"`` — ``torch.profiler`` (roctracer underneath on ROCm): per-kernel GPU rows with
-  stream ids, RCCL kernels, ``ProfilerStep#N`` annotations. What ``analyze_traces.py`` wants.
-* ``"range"`` — the native range tracer (``csrc/runtime/range_tracer.cpp``): named host + GPU
-  ranges only (forward / backward / optimizer / all-gather wait ...), negligible overhead,
-  mirrored to roctx so ``rocprofv3 --marker-trace`` sees the same annotations.
-* ``"auto"`` — kineto when a GPU is present, range otherwise.
+* ``"range"`` (the default) — the framework's own tracer (``csrc/runtime/range_tracer.cpp``):
+  ``ProfilerStep#N`` plus named host + GPU ranges for forward / backward / optimizer (emitted by
+  the trainers through :func:`annotate`) and for all-gather wait / reduce-scatter launch /
+  end-of-backward reduction wait (emitted by the C++ DDP / FSDP runtime itself), at negligible
+  overhead. Every range is mirrored to roctx, so when the run is wrapped in
+  ``rocprofv3 --kernel-trace --marker-trace`` the kernel rows and these ranges share one clock and
+  ``utils/rocprof_trace.py`` (``analyze_traces.py --from-rocprof``) merges them into the per-rank
+  Chrome trace with the collectives on a row of their own — the kernel-level trace without Kineto.
+* ``"kineto"`` — ``torch.profiler`` (roctracer underneath on ROCm), kept for comparison.
+* ``"auto"`` — the same as ``"range"``.
 
-``profiler.range("name")`` annotates a phase under either backend.
+``profiler.range("name")`` / module-level ``annotate("name")`` annotate a phase under either backend.
 """
 from __future__ import annotations
 
@@ -28,12 +32,27 @@ import torch
 from .. import _ext
 
 
+_ACTIVE: Optional["StepProfiler"] = None
+
+
+@contextlib.contextmanager
+def annotate(name: str):
+    """Named range in the active :class:`StepProfiler` (no-op when none is active): what the
+    trainers and wrappers call, so their phases show up without holding a profiler object."""
+    prof = _ACTIVE
+    if prof is None:
+        yield
+        return
+    with prof.range(name):
+        yield
+
+
 class StepProfiler:
     def __init__(self, wait: int = 2, warmup: int = 2, active: int = 6, repeat: int = 1,
                  trace_path: Optional[str] = None, backend: str = "auto", rank: int = 0,
                  record_shapes: bool = False):
         if backend == "auto":
-            backend = "kineto" if torch.cuda.is_available() else "range"
+            backend = "range"
         if backend not in ("kineto", "range"):
             raise ValueError("backend must be 'auto', 'kineto' or 'range'")
         self.wait, self.warmup, self.active, self.repeat = wait, warmup, active, repeat
@@ -77,18 +96,27 @@ class StepProfiler:
 
     # -- context manager -----------------------------------------------------------------
     def __enter__(self):
+        global _ACTIVE
+        _ACTIVE = self
         if self._kineto is not None:
             self._kineto.__enter__()
         else:
+            self._tracer.activate()  # the C++ runtime's own ranges land in this tracer
+            self._tracer.push(f"pda.rank={self.rank}", "meta")  # lets a rocprofv3 marker trace name its rank
+            self._tracer.pop()
             self._begin_step()
         return self
 
     def __exit__(self, *exc):
+        global _ACTIVE
         if self._kineto is not None:
             self._kineto.__exit__(*exc)
         else:
             self._end_step()
             self._flush_range_trace()
+            self._tracer.deactivate()
+        if _ACTIVE is self:
+            _ACTIVE = None
         return False
 
     def _begin_step(self) -> None:

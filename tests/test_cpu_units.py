@@ -387,3 +387,41 @@ def test_init_on_device_meta_and_dtype():
     assert torch.get_default_dtype() == torch.float32
     ids = torch.randint(0, 512, (2, 17))
     assert torch.isfinite(m(ids[:, :-1], ids[:, 1:]).float())
+
+
+def test_rocprof_trace_merge_builds_per_rank_chrome_traces(tmp_path):
+    """rocprofv3 kernel + marker CSVs -> rank{r}_trace.json: collectives on their own row, ranges as
+    user annotations, usable by the analyzer (breakdown, overlap, ProfilerStep window)."""
+    from pytorch_distributed_amd.utils import rocprof_trace, trace_analysis as ta
+
+    d = tmp_path / "prof" / "host"
+    d.mkdir(parents=True)
+    kernel_hdr = '"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp","Grid_Size_X","Workgroup_Size_X"\n'
+    marker_hdr = '"Domain","Function","Process_Id","Thread_Id","Correlation_Id","Start_Timestamp","End_Timestamp"\n'
+    for pid, rank in ((501, 1), (500, 0)):
+        base = 1_000_000 * (rank + 1)
+        (d / f"{pid}_kernel_trace.csv").write_text(kernel_hdr + "".join([
+            f'"KERNEL_DISPATCH","Agent 1",1,0,{pid},1,10,"Cijk_gemm",1,{base + 100_000},{base + 140_000},65536,256\n',
+            f'"KERNEL_DISPATCH","Agent 1",2,3,{pid},2,11,"ncclDevKernel_Generic_4(ncclDevKernelArgs)",2,{base + 130_000},{base + 170_000},4096,256\n',
+            f'"KERNEL_DISPATCH","Agent 1",1,0,{pid},3,12,"pda::attn_fwd_kernel",3,{base + 150_000},{base + 170_000},65536,256\n',
+            f'"KERNEL_DISPATCH","Agent 1",1,0,{pid},4,12,"pda::attn_fwd_kernel",4,{base + 900_000},{base + 910_000},65536,256\n']))
+        (d / f"{pid}_marker_api_trace.csv").write_text(marker_hdr + "".join([
+            f'"MARKER_CORE_API","pda.rank={rank}",{pid},{pid},1,{base},{base + 10}\n',
+            f'"MARKER_CORE_API","ProfilerStep#4",{pid},{pid},2,{base + 100_000},{base + 200_000}\n',
+            f'"MARKER_CORE_API","forward",{pid},{pid},3,{base + 100_000},{base + 120_000}\n',
+            f'"MARKER_CORE_API","all_gather wait",{pid},{pid + 7},4,{base + 125_000},{base + 126_000}\n']))
+    written = rocprof_trace.merge(str(tmp_path / "prof"), str(tmp_path / "traces" / "ddp"), only_profiler_steps=True)
+    assert sorted(written) == [0, 1] and written[1].endswith("rank1_trace.json")
+    ev = ta.load_trace(written[0])
+    kernels = [e for e in ev if e.get("cat") == "kernel"]
+    assert len(kernels) == 3  # the kernel after the profiler window was dropped
+    assert {e["tid"] for e in kernels if "nccl" in e["name"]} == {rocprof_trace.COLLECTIVE_ROW}
+    assert {e["tid"] for e in kernels if "nccl" not in e["name"]} == {100}
+    names = {e["name"] for e in ev if e.get("cat") == "user_annotation"}
+    assert names == {"ProfilerStep#4", "forward", "all_gather wait"}
+    o = ta.comm_comp_overlap(ev, step=4)
+    assert o["comm_us"] == 40.0 and o["overlapped_us"] == 30.0  # 130-140 with the GEMM, 150-170 with attention
+    b = ta.temporal_breakdown(ev, step=4)
+    assert b["compute_us"] == 60.0 and b["non_compute_us"] == 10.0
+    res = ta.analyze_dir(str(tmp_path / "traces" / "ddp"))
+    assert set(res) == {0, 1}
