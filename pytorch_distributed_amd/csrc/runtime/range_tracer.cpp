@@ -49,8 +49,13 @@ struct Roctx {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
   Roctx() {
-    void* lib = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
+    // rocprofv3 listens to the rocprofiler-sdk build of ROCTx; the roctracer build serves older tools.
+    void* lib = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1",
+                             "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "libroctx64.so.4"}) {
+      lib = dlopen(name, RTLD_LAZY | RTLD_GLOBAL);
+      if (lib) break;
+    }
     if (!lib) return;
     push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
     pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
@@ -248,9 +253,11 @@ namespace trace {
 
 bool active() { return g_active.load(std::memory_order_relaxed) != nullptr; }
 
-void push(const char* name, const char* cat) {
+bool push(const char* name, const char* cat) {
   RangeTracer* t = g_active.load();
-  if (t != nullptr && t->enabled()) t->push(name, cat);
+  if (t == nullptr || !t->enabled()) return false;
+  t->push(name, cat);
+  return true;
 }
 
 void pop() {

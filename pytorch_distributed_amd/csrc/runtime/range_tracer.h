@@ -7,14 +7,12 @@ namespace pda {
 namespace trace {
 
 bool active();
-void push(const char* name, const char* cat);
+bool push(const char* name, const char* cat);  // false: no tracer is recording, nothing was opened
 void pop();
 
 class Scope {
  public:
-  explicit Scope(const char* name, const char* cat = "runtime") : on_(active()) {
-    if (on_) push(name, cat);
-  }
+  explicit Scope(const char* name, const char* cat = "runtime") : on_(active() && push(name, cat)) {}
   ~Scope() {
     if (on_) pop();
   }

@@ -24,7 +24,7 @@ import re
 from collections import defaultdict
 from typing import Dict, Iterable, List, Optional, Tuple
 
-COMM_PATTERN = re.compile(r"nccl|rccl|all_?reduce|all_?gather|reduce_?scatter|broadcast|sendrecv", re.I)
+COMM_PATTERN = re.compile(r"nccl|rccl|all_?reduce|all_?gather|reduce_?scatter|broadcast|sendrecv|onerankreduce", re.I)
 GPU_CATS = {"kernel", "gpu_memcpy", "gpu_memset"}
 MEM_CATS = {"gpu_memcpy", "gpu_memset"}
 

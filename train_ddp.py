@@ -19,10 +19,11 @@ from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
-def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False, decompose=None):
+def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False, decompose=None, force_collectives=False):
     """``model`` (already on ``device``) wrapped in DDP (None = the start-up measurement's choice)."""
     ids = [device.index] if device.type == "cuda" else None
-    return DDP(model, device_ids=ids, reduce_fp32=reduce_fp32, bucket_cap_mb=bucket_cap_mb, decompose=decompose)
+    return DDP(model, device_ids=ids, reduce_fp32=reduce_fp32, bucket_cap_mb=bucket_cap_mb, decompose=decompose,
+               force_collectives=force_collectives)
 
 
 def main():
@@ -31,6 +32,8 @@ def main():
     ap.add_argument("--ddp-decompose", choices=["auto", "on", "off"], default="auto",
                     help="reduce buckets as reduce-scatter + all-gather instead of all-reduce (auto: measured)")
     ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="issue the collectives even at world size 1 (single-GPU rehearsal of the communication path)")
     ap.add_argument("--backend", default=None, choices=[None, "rccl", "socket", "c10d", "nccl", "gloo"])
     ap.add_argument("--reduce-fp32", action="store_true", help="all-reduce bf16 gradients through an fp32 copy")
     args = ap.parse_args()
@@ -46,7 +49,7 @@ def main():
     if device.type == "cuda" and dtype == torch.bfloat16:
         plan_sync.plan_gemms(model, args.micro_batch_size, args.sequence_length, cfg.vocab_size)
     model = setup_ddp_model(model, device, args.bucket_mb, args.reduce_fp32,
-                            {"auto": None, "on": True, "off": False}[args.ddp_decompose])
+                            {"auto": None, "on": True, "off": False}[args.ddp_decompose], args.force_collectives)
     if rank == 0:
         print(f"Model wrapped with DDP ({model.reducer.num_buckets} gradient buckets of <= {model.bucket_cap_mb:g} MiB"
               f"{', reduce-scatter + all-gather' if model.decompose else ''})")

@@ -20,15 +20,17 @@ from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
-def setup_fsdp_model(model, device, sharding_strategy_name="FULL_SHARD", unit_blocks=1, reduce_fp32=False):
+def setup_fsdp_model(model, device, sharding_strategy_name="FULL_SHARD", unit_blocks=1, reduce_fp32=False,
+                     force_collectives=False):
     """Per-block wrapping plus the root unit (the reference's layout when ``unit_blocks == 1``)."""
     model = model.to(device)
     strategy = ShardingStrategy[sharding_strategy_name]
+    kw = dict(reduce_fp32=reduce_fp32, force_collectives=force_collectives)
     if unit_blocks == 1:
         for i, block in enumerate(model.transformer.h):
-            model.transformer.h[i] = FSDP(block, sharding_strategy=strategy, reduce_fp32=reduce_fp32)
-        return FSDP(model, sharding_strategy=strategy, reduce_fp32=reduce_fp32)
-    return fsdp_wrap_gpt(model, strategy, unit_blocks=unit_blocks, reduce_fp32=reduce_fp32)
+            model.transformer.h[i] = FSDP(block, sharding_strategy=strategy, **kw)
+        return FSDP(model, sharding_strategy=strategy, **kw)
+    return fsdp_wrap_gpt(model, strategy, unit_blocks=unit_blocks, **kw)
 
 
 def main():
@@ -38,6 +40,8 @@ def main():
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None,
                     help="transformer blocks per sharding unit (default: from the start-up measurement)")
     ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="issue the collectives even at world size 1 (single-GPU rehearsal of the communication path)")
     ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
     ap.add_argument("--backend", default=None, choices=[None, "rccl", "socket", "c10d", "nccl", "gloo"])
     ap.add_argument("--sharded-checkpoint", default=None,
@@ -58,7 +62,7 @@ def main():
         blocks = model.transformer.h
         block_bytes = sum(p.numel() * p.element_size() for p in blocks[0].parameters())
         unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
-    model = setup_fsdp_model(model, device, args.strategy, unit_blocks, args.reduce_fp32)
+    model = setup_fsdp_model(model, device, args.strategy, unit_blocks, args.reduce_fp32, args.force_collectives)
     if rank == 0:
         print(f"Model wrapped with FSDP ({args.strategy}, {unit_blocks} block(s) per unit)")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
