@@ -470,7 +470,87 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
 
 }  // namespace
 
+// -------------------------------------------------------------- embedding --
+at::Tensor embedding_forward(const at::Tensor& ids, const at::Tensor& wte, const std::optional<at::Tensor>& wpe) {
+  check_gpu(wte, "wte");
+  TORCH_CHECK(ids.is_cuda() && ids.is_contiguous() && ids.scalar_type() == at::kLong, "embedding: ids must be a contiguous int64 GPU tensor");
+  TORCH_CHECK(ids.dim() == 2 && wte.dim() == 2, "embedding: ids [B, T], wte [V, d]");
+  const c10::DeviceGuard guard(wte.device());
+  const auto dt = dtype_of(wte);
+  const int64_t d = wte.size(1), T = ids.size(1);
+  TORCH_CHECK(d % (dt == pda::kBF16 ? 8 : 4) == 0, "embedding: row length ", d, " is not a multiple of the 16-byte vector");
+  TORCH_CHECK(wte.size(0) < (int64_t(1) << 31) && ids.numel() < (int64_t(1) << 31), "embedding: table or batch too large");
+  const void* wpe_ptr = nullptr;
+  if (wpe.has_value()) {
+    check_gpu(*wpe, "wpe");
+    TORCH_CHECK(wpe->dim() == 2 && wpe->size(1) == d && wpe->size(0) >= T && wpe->scalar_type() == wte.scalar_type(),
+                "embedding: wpe must be [>= T, d] in the dtype of wte");
+    wpe_ptr = wpe->data_ptr();
+  }
+  at::Tensor out = at::empty({ids.size(0), T, d}, wte.options());
+  pda::embedding_forward(dt, ids.data_ptr<int64_t>(), wte.data_ptr(), wpe_ptr, out.data_ptr(), ids.numel(), (int)T, (int)d,
+                         (int)wte.size(0), current_stream());
+  check_launch("embedding_forward");
+  return out;
+}
+
+// Gradients of embedding_forward. dwte_out / dwpe_out (optional): existing gradient buffers to
+// write (accumulate = false) or add into (accumulate = true); without them fresh tensors are
+// returned (dwte zero-initialised, then the rows of occurring tokens written).
+std::vector<at::Tensor> embedding_backward(const at::Tensor& ids, const at::Tensor& dout, int64_t vocab, bool need_wpe,
+                                           int64_t wpe_rows, const std::optional<at::Tensor>& dwte_out, bool wte_accumulate,
+                                           const std::optional<at::Tensor>& dwpe_out, bool wpe_accumulate) {
+  check_gpu(dout, "dout");
+  TORCH_CHECK(ids.is_cuda() && ids.is_contiguous() && ids.scalar_type() == at::kLong && ids.dim() == 2,
+              "embedding: ids must be a contiguous int64 [B, T] GPU tensor");
+  const c10::DeviceGuard guard(dout.device());
+  const auto dt = dtype_of(dout);
+  const int64_t B = ids.size(0), T = ids.size(1), d = dout.size(-1);
+  TORCH_CHECK(dout.numel() == B * T * d, "embedding: dout must be [B, T, d]");
+  TORCH_CHECK(d % (dt == pda::kBF16 ? 8 : 4) == 0, "embedding: bad row length ", d);
+  TORCH_CHECK(vocab > 0 && vocab < (int64_t(1) << 31) && B * T < (int64_t(1) << 31), "embedding: table or batch too large");
+  at::Tensor dwte;
+  bool acc_w = false;
+  if (dwte_out.has_value()) {
+    dwte = *dwte_out;
+    check_gpu(dwte, "dwte_out");
+    TORCH_CHECK(dwte.scalar_type() == dout.scalar_type() && dwte.numel() == vocab * d, "embedding: dwte_out must be [V, d] in dout's dtype");
+    acc_w = wte_accumulate;
+    if (!acc_w) dwte.zero_();
+  } else {
+    dwte = at::zeros({vocab, d}, dout.options());
+  }
+  const size_t ws_bytes = pda::embedding_backward_workspace_bytes((int)(B * T), (int)vocab);
+  at::Tensor ws = at::empty({(int64_t)ws_bytes}, dout.options().dtype(at::kByte));
+  pda::embedding_backward_wte(dt, ids.data_ptr<int64_t>(), dout.data_ptr(), dwte.data_ptr(), acc_w, (int)(B * T), (int)d,
+                              (int)vocab, ws.data_ptr(), ws_bytes, current_stream());
+  check_launch("embedding_backward_wte");
+  std::vector<at::Tensor> result{dwte};
+  if (need_wpe) {
+    TORCH_CHECK(wpe_rows >= T, "embedding: position table shorter than the sequence");
+    at::Tensor dwpe;
+    bool acc_p = false;
+    if (dwpe_out.has_value()) {
+      dwpe = *dwpe_out;
+      check_gpu(dwpe, "dwpe_out");
+      TORCH_CHECK(dwpe.scalar_type() == dout.scalar_type() && dwpe.numel() == wpe_rows * d, "embedding: dwpe_out must be [n_ctx, d]");
+      acc_p = wpe_accumulate;
+      if (!acc_p && wpe_rows > T) dwpe.narrow(0, T, wpe_rows - T).zero_();
+    } else {
+      dwpe = wpe_rows > T ? at::zeros({wpe_rows, d}, dout.options()) : at::empty({wpe_rows, d}, dout.options());
+    }
+    pda::embedding_backward_wpe(dt, dout.data_ptr(), dwpe.data_ptr(), acc_p, (int)B, (int)T, (int)d, current_stream());
+    check_launch("embedding_backward_wpe");
+    result.push_back(dwpe);
+  }
+  return result;
+}
+
 void bind_ops(py::module_& m) {
+  m.def("embedding_forward", &embedding_forward, py::arg("ids"), py::arg("wte"), py::arg("wpe") = py::none());
+  m.def("embedding_backward", &embedding_backward, py::arg("ids"), py::arg("dout"), py::arg("vocab"), py::arg("need_wpe"),
+        py::arg("wpe_rows") = 0, py::arg("dwte_out") = py::none(), py::arg("wte_accumulate") = false,
+        py::arg("dwpe_out") = py::none(), py::arg("wpe_accumulate") = false);
   m.def("rope_apply", &rope_apply, py::arg("qkv"), py::arg("cos"), py::arg("sin"), py::arg("num_heads"),
         py::arg("inverse"), py::arg("in_place"));
   m.def("transpose_2d", &transpose_2d, py::arg("src"), py::arg("pad_rows_to") = 8);

@@ -131,6 +131,21 @@ void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, v
                   const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
                   bool bias_accumulate, hipStream_t stream);
 
+// ----------------------------------------------------------------- Embedding --
+// out[n, :] = wte[ids[n], :] (+ wpe[n mod T, :] when wpe != nullptr). d % (16 / sizeof(T)) == 0.
+void embedding_forward(DType dtype, const int64_t* ids, const void* wte, const void* wpe, void* out, int64_t n_tokens,
+                       int T_len, int d, int vocab, hipStream_t stream);
+// dwte[v, :] (+)= sum of dout rows whose token is v: deterministic (stable sort by token, one
+// writer per row), launch shapes depend on n_tokens only. Rows of dwte whose token does not occur
+// are left untouched (zero them first unless accumulating). `workspace` needs
+// embedding_backward_workspace_bytes(n_tokens, vocab) bytes.
+size_t embedding_backward_workspace_bytes(int n_tokens, int vocab);
+void embedding_backward_wte(DType dtype, const int64_t* ids, const void* dout, void* dwte, bool accumulate, int n_tokens,
+                            int d, int vocab, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// dwpe[t, :] (+)= sum over the batch of dout[b, t, :].
+void embedding_backward_wpe(DType dtype, const void* dout, void* dwpe, bool accumulate, int batch, int T_len, int d,
+                            hipStream_t stream);
+
 // ----------------------------------------------------------------- Utilities --
 // dst(fp32) += src(bf16) * scale, and plain casts, for main-grad accumulation.
 void accumulate_bf16_into_f32(const void* src_bf16, float* dst, int64_t n, float scale, hipStream_t stream);

@@ -142,10 +142,9 @@ class MyGPT2Model(nn.Module):
         _, seq_len = input_ids.shape
         if seq_len > self.n_ctx:
             raise ValueError(f"sequence length {seq_len} exceeds n_ctx {self.n_ctx}")
-        positions = torch.arange(seq_len, device=input_ids.device)
-        # Embedding dropout, like every residual dropout below, is applied inside the LayerNorm
-        # kernel that consumes the tensor (`delta_pdrop`).
-        delta = ops.embedding(input_ids, self.wte.weight) + self.wpe(positions)
+        # Token + position lookup in one kernel. Embedding dropout, like every residual dropout
+        # below, is applied inside the LayerNorm kernel that consumes the tensor (`delta_pdrop`).
+        delta = ops.token_position_embedding(input_ids, self.wte.weight, self.wpe.weight)
         pdrop = self.drop.p
         residual = None
         full_recompute = (self.enable_activation_checkpoint and self.training

@@ -11,7 +11,9 @@ assignments/assignment1/train/trainer.py:53-56) — as:
 2. one HIP kernel that reads each logits row once, produces the per-row loss
    and overwrites the row with ``(softmax - onehot) / n_valid`` — the gradient
    with respect to the logits is already in place when backward starts;
-3. in backward, the two GEMMs for ``dhidden`` and ``dweight``.
+3. in backward, the two GEMMs for ``dhidden`` and ``dweight``; when the (tied) weight belongs to
+   a DDP bucket or an FSDP unit, ``dweight`` is produced straight into the owner's gradient
+   buffer (gradient sink) and the embedding backward later adds its rows to the same buffer.
 
 fp32 logits (1.65 GB at B=8, T=1024 for GPT-2) are never materialised.
 """
@@ -21,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _ext
-from .linear import input_grad_mm, planned_mm
+from .linear import _grad_target, input_grad_mm, planned_mm
 
 _PAD = 128
 
@@ -84,6 +86,7 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
         row_loss = ext.cross_entropy_fwd_bwd(logits[:, :V], tgt, V, scale, ignore_index)
         ctx.save_for_backward(logits, h2, weight)
         ctx.hidden_shape = hidden.shape
+        ctx.grad_sink = getattr(weight, "_pda_grad_sink", None)
         return row_loss.sum() * scale[0]
 
     @staticmethod
@@ -95,7 +98,16 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dhidden = input_grad_mm(dlogits, weight, dlogits_p).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
         if ctx.needs_input_grad[1]:
-            dweight = torch.mm(dlogits.t(), h2).mul_(dloss.to(weight.dtype))
+            target = _grad_target(weight, ctx.grad_sink)
+            if target is not None and not target[1] and target[0].is_contiguous():
+                # first writer of the owner's slot in this pass: the GEMM writes it, dloss is applied to
+                # the small operand instead of a pass over the [V, d] result
+                torch.mm(dlogits.t(), h2 * dloss.to(weight.dtype), out=target[0])
+            else:
+                dweight = torch.mm(dlogits.t(), h2).mul_(dloss.to(weight.dtype))
+                if target is not None:
+                    target[0].add_(dweight)
+                    dweight = None
         return dhidden, dweight, None, None
 
 

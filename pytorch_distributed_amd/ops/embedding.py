@@ -1,39 +1,83 @@
-"""Token-embedding lookup whose backward is safe inside a HIP graph capture.
+"""Token (+ position) embedding on the native gfx950 kernels (``csrc/kernels/embedding.hip``).
 
-Eager mode is PyTorch's own path (``embedding_dense_backward``: sort the indices, segment them with
-a unique-by-key, reduce each segment — deterministic). Replaying that path from a captured graph
-was the one place a whole-step replay was seen to fault (its segmenting kernels are sized from the
-data of the capturing step), so while a capture is in progress the weight gradient is instead built
-by ``index_add_`` into an fp32 buffer: plain atomic adds, nothing data-dependent in the launch.
-The summation order of the atomics is not fixed, so graph replays are not bit-reproducible in
-this gradient; eager runs are.
+``token_position_embedding(ids, wte, wpe)`` is the reference's ``wte(ids) + wpe(arange(T))``
+(assignments/assignment1/model/my_gpt2.py:166-172) as one lookup kernel; ``embedding(ids, weight)``
+is the plain lookup (the Llama-style models have no position table).
+
+Backward is the part that matters. The token-table gradient is a scatter-add with collisions;
+PyTorch's ``embedding_dense_backward`` sorts and segments the indices with launches whose shape
+depends on the token VALUES, which cannot be replayed from a HIP graph with other tokens. The
+native backward sorts (token, position) pairs with a stable radix sort and lets exactly one wave
+sum each run of equal tokens in position order: no float atomics (bit-reproducible), launch shapes
+that depend on the token count only (graph-capture safe), and the result is written — or, for the
+tied LM-head weight, added — straight into the owner's gradient buffer (gradient sink), so no
+``[V, d]`` temporary is created under DDP / FSDP.
+
+CPU tensors and ``PDA_FORCE_REFERENCE=1`` use ``torch.nn.functional.embedding``.
 """
 from __future__ import annotations
+
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
+from .. import _ext
+
+
+def _grad_target(param, sink):
+    """Where a parameter's gradient should be written: ``(tensor, accumulate)`` from the owner's sink,
+    else an existing contiguous ``.grad`` (accumulate), else None (fresh tensor handed to autograd)."""
+    target = sink() if sink is not None else None
+    if target is None and param.grad is not None and param.grad.is_contiguous():
+        target = (param.grad, True)
+    return target
+
 
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, weight):
+    def forward(ctx, ids, wte, wpe):
+        ext = _ext.require()
+        ids = ids.contiguous()
         ctx.save_for_backward(ids)
-        ctx.rows = weight.shape[0]
-        return F.embedding(ids, weight)
+        ctx.wte, ctx.wpe = wte, wpe  # consulted for .grad / the gradient sink only
+        ctx.wte_sink = getattr(wte, "_pda_grad_sink", None)
+        ctx.wpe_sink = getattr(wpe, "_pda_grad_sink", None) if wpe is not None else None
+        return ext.embedding_forward(ids, wte, wpe)
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
-        d = grad.shape[-1]
-        if grad.is_cuda and torch.cuda.is_current_stream_capturing():
-            acc = torch.zeros(ctx.rows, d, dtype=torch.float32, device=grad.device)
-            acc.index_add_(0, ids.reshape(-1), grad.reshape(-1, d).float())
-            return None, acc.to(grad.dtype)
-        return None, torch.ops.aten.embedding_dense_backward(grad, ids, ctx.rows, -1, False)
+        ext = _ext.require()
+        wte, wpe = ctx.wte, ctx.wpe
+        need_wte = ctx.needs_input_grad[1]
+        need_wpe = wpe is not None and ctx.needs_input_grad[2]
+        if not need_wte:  # frozen table: only the position gradient (rare); use the dense path for it
+            dwpe = dout.sum(0) if need_wpe else None
+            if need_wpe and dwpe.shape[0] < wpe.shape[0]:
+                dwpe = F.pad(dwpe, (0, 0, 0, wpe.shape[0] - dwpe.shape[0]))
+            return None, None, dwpe
+        w_target = _grad_target(wte, ctx.wte_sink)
+        p_target = _grad_target(wpe, ctx.wpe_sink) if need_wpe else None
+        w_out, w_acc = w_target if w_target is not None else (None, False)
+        p_out, p_acc = p_target if p_target is not None else (None, False)
+        res = ext.embedding_backward(ids, dout.contiguous(), wte.shape[0], need_wpe,
+                                     wpe.shape[0] if need_wpe else 0, w_out, w_acc, p_out, p_acc)
+        dwte = res[0] if w_target is None else None
+        dwpe = (res[1] if p_target is None else None) if need_wpe else None
+        return None, dwte, dwpe
+
+
+def token_position_embedding(ids: torch.Tensor, wte: torch.Tensor, wpe: Optional[torch.Tensor]) -> torch.Tensor:
+    """``wte[ids] + wpe[arange(T)]`` for ``ids [B, T]`` (``wpe=None``: the lookup alone)."""
+    if _ext.use_hip(wte) and wte.dtype in (torch.bfloat16, torch.float32) and ids.dim() == 2:
+        return _EmbeddingFn.apply(ids, wte, wpe)
+    out = F.embedding(ids, wte)
+    if wpe is not None:
+        out = out + wpe[: ids.shape[-1]]
+    return out
 
 
 def embedding(ids: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """``weight[ids]`` (``torch.nn.functional.embedding`` semantics, no padding index)."""
-    if weight.is_cuda and weight.requires_grad and torch.is_grad_enabled():
-        return _EmbeddingFn.apply(ids, weight)
-    return F.embedding(ids, weight)
+    return token_position_embedding(ids, weight, None)

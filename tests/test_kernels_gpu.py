@@ -447,3 +447,59 @@ def test_gpt2_trains_with_dropout():
     model.eval()
     with torch.no_grad():
         assert model(ids[:, :-1], ids[:, 1:]).item() == model(ids[:, :-1], ids[:, 1:]).item()
+
+
+# ------------------------------------------------------------------ embedding
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V,d,B,T", [(50257, 768, 4, 1024), (512, 128, 3, 37), (50257, 1600, 2, 1024)])
+def test_embedding_forward_backward_match_fp32_reference(dtype, V, d, B, T):
+    """Fused token + position lookup and its deterministic scatter backward against an fp32 PyTorch
+    reference on the same (rounded) inputs; skewed token frequencies so runs of equal tokens are long."""
+    from pytorch_distributed_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(V + d)
+    wte = (torch.randn(V, d, generator=g) * 0.02).to(dtype).to(DEV).requires_grad_(True)
+    wpe = (torch.randn(1024, d, generator=g) * 0.01).to(dtype).to(DEV).requires_grad_(True)
+    # a quarter of the positions use five very frequent tokens, the rest are uniform
+    ids = torch.randint(0, V, (B, T), generator=g)
+    hot = torch.rand(B, T, generator=g) < 0.25
+    ids[hot] = torch.randint(0, 5, (int(hot.sum()),), generator=g)
+    ids = ids.to(DEV)
+    dout = torch.randn(B, T, d, generator=g).to(dtype).to(DEV)
+
+    out = ops.token_position_embedding(ids, wte, wpe)
+    ref_w, ref_p = wte.detach().float().requires_grad_(True), wpe.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.embedding(ids, ref_w) + ref_p[:T]
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
+    assert (out.float() - ref).abs().max().item() <= tol * 0.1
+    out.backward(dout)
+    ref.backward(dout.float())
+    assert rel_err(wte.grad, ref_w.grad) < (6e-3 if dtype == torch.bfloat16 else 1e-6)
+    assert rel_err(wpe.grad, ref_p.grad) < (6e-3 if dtype == torch.bfloat16 else 1e-6)
+    assert wpe.grad[T:].abs().max().item() == 0.0 if T < 1024 else True
+    # untouched rows are exactly zero, and the result is bit-reproducible
+    untouched = torch.ones(V, dtype=torch.bool, device=DEV)
+    untouched[ids.reshape(-1)] = False
+    assert wte.grad[untouched].abs().max().item() == 0.0
+    first = wte.grad.clone()
+    wte.grad = None
+    wpe.grad = None
+    ops.token_position_embedding(ids, wte, wpe).backward(dout)
+    assert torch.equal(wte.grad, first)
+
+
+def test_embedding_backward_accumulates_into_an_existing_gradient():
+    """The tied LM-head weight already holds a gradient when the embedding backward runs: rows are
+    added in place, everything else is left alone."""
+    from pytorch_distributed_amd import ops
+
+    V, d, B, T = 1000, 256, 2, 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    wte = torch.randn(V, d, generator=g).to(torch.bfloat16).to(DEV).requires_grad_(True)
+    ids = torch.randint(0, V, (B, T), generator=g).to(DEV)
+    dout = torch.randn(B, T, d, generator=g).to(torch.bfloat16).to(DEV)
+    existing = torch.randn(V, d, generator=g).to(torch.bfloat16).to(DEV)
+    wte.grad = existing.clone()
+    ops.embedding(ids, wte).backward(dout)
+    ref = existing.float().index_add(0, ids.reshape(-1), dout.reshape(-1, d).float())
+    assert rel_err(wte.grad, ref) < 6e-3

@@ -148,3 +148,37 @@ def test_full_recompute_reproduces_dropout_masks():
     assert grads[0][0] == grads[1][0]
     for n, g in grads[0][1].items():
         assert rel_err(grads[1][1][n], g) < 1e-3, n
+
+
+def test_graphed_train_step_at_the_gpt2_vocabulary_with_fresh_tokens_every_replay():
+    """Whole-step HIP-graph replay at the size class where a replay once faulted: GPT-2 vocabulary
+    (50257), 4096 tokens per micro-batch, 2 micro-batches, token ids that change on every replay.
+    The native embedding backward has no data-dependent launch, so the replays must track eager."""
+    from pytorch_distributed_amd.utils.graphs import GraphedTrainStep
+
+    cfg = get_config("gpt2", n_layer=2).without_dropout()
+    torch.manual_seed(0)
+    ref = MyGPT2LMHeadModel(cfg).to(device=DEV, dtype=torch.bfloat16)
+    mod = MyGPT2LMHeadModel(cfg).to(device=DEV, dtype=torch.bfloat16)
+    mod.load_state_dict(ref.state_dict())
+    opt_ref = FusedAdamW(ref.parameters(), lr=3e-4, weight_decay=0.1)
+    opt = FusedAdamW(mod.parameters(), lr=3e-4, weight_decay=0.1, capturable=True)
+    B, T, accum = 4, 1024, 2
+    graphed = GraphedTrainStep(mod, opt, B, T, accum, warmup_steps=1)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for step in range(7):  # 1 eager warm-up, 1 capture, 5 replays
+        buf = torch.randint(0, cfg.vocab_size, (accum * B, T + 1), generator=g)
+        if step % 2:  # skewed steps: long runs of equal tokens in the sorted order
+            buf[:, ::3] = torch.randint(0, 4, buf[:, ::3].shape, generator=g)
+        x, y = buf[:, :-1].contiguous().to(DEV), buf[:, 1:].contiguous().to(DEV)
+        total = 0.0
+        for i in range(accum):
+            loss = ref(x[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) / accum
+            loss.backward()
+            total += float(loss.detach())
+        opt_ref.step(zero_grad=True)
+        got = float(graphed(x, y))
+        assert abs(got - total) < 2e-2 * max(1.0, abs(total)), (step, got, total)
+    torch.cuda.synchronize()
+    assert rel_err(ref.transformer.wte.weight, mod.transformer.wte.weight) < 2e-2
+    assert rel_err(ref.transformer.h[0].mlp.c_fc.weight, mod.transformer.h[0].mlp.c_fc.weight) < 2e-2
