@@ -470,6 +470,61 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
 
 }  // namespace
 
+// ------------------------------------------------------- fused-epilogue GEMM --
+void check_bf16_matrix(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.defined() && t.is_cuda() && t.scalar_type() == at::kBFloat16, name, " must be a bf16 GPU tensor");
+  TORCH_CHECK(t.dim() == 2 && t.stride(1) == 1 && t.stride(0) >= t.size(1) && t.stride(0) % 8 == 0, name,
+              " must be a row-major matrix with unit column stride and a row stride that is a multiple of 8");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, " must be 16-byte aligned");
+}
+
+bool gemm_fused_supported(int64_t M, int64_t N, int64_t K) {
+  return M < (int64_t(1) << 31) && N < (int64_t(1) << 31) && pda::gemm_fused_supported((int)M, (int)N, (int)K);
+}
+
+// epilogue: "none" | "bias" | "bias_gelu" (returns [u, gelu(u)]) | "mul_gelu_grad" (aux = u, returns [acc * gelu'(u)]).
+std::vector<at::Tensor> gemm_fused(const at::Tensor& x, const at::Tensor& w, const std::optional<at::Tensor>& bias,
+                                   const std::string& epilogue, const std::optional<at::Tensor>& aux) {
+  check_bf16_matrix(x, "x");
+  check_bf16_matrix(w, "w");
+  const c10::DeviceGuard guard(x.device());
+  const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
+  TORCH_CHECK(w.size(1) == K, "gemm_fused: x is [M, K], w must be [N, K]");
+  TORCH_CHECK(gemm_fused_supported(M, N, K), "gemm_fused: unsupported shape M=", M, " N=", N, " K=", K,
+              " (needs K % 32 == 0 and N % 8 == 0)");
+  int epi = pda::kEpiNone;
+  if (epilogue == "bias") epi = pda::kEpiBias;
+  else if (epilogue == "bias_gelu") epi = pda::kEpiBiasGelu;
+  else if (epilogue == "mul_gelu_grad") epi = pda::kEpiMulGeluGrad;
+  else TORCH_CHECK(epilogue == "none", "gemm_fused: unknown epilogue '", epilogue, "'");
+  const void* bias_ptr = nullptr;
+  if (epi == pda::kEpiBias || epi == pda::kEpiBiasGelu) {
+    TORCH_CHECK(bias.has_value() && bias->is_cuda() && bias->scalar_type() == at::kBFloat16 && bias->is_contiguous() &&
+                    bias->numel() == N && reinterpret_cast<uintptr_t>(bias->data_ptr()) % 8 == 0,
+                "gemm_fused: bias must be a contiguous, 8-byte aligned bf16 GPU vector of length ", N);
+    bias_ptr = bias->data_ptr();
+  }
+  at::Tensor out = at::empty({M, N}, x.options());
+  std::vector<at::Tensor> result{out};
+  void* aux_ptr = nullptr;
+  int64_t ldaux = N;
+  if (epi == pda::kEpiBiasGelu) {
+    at::Tensor act = at::empty({M, N}, x.options());
+    aux_ptr = act.data_ptr();
+    result.push_back(act);
+  } else if (epi == pda::kEpiMulGeluGrad) {
+    TORCH_CHECK(aux.has_value(), "gemm_fused: 'mul_gelu_grad' needs the pre-activation as aux");
+    check_bf16_matrix(*aux, "aux");
+    TORCH_CHECK(aux->size(0) == M && aux->size(1) == N, "gemm_fused: aux must be [M, N]");
+    aux_ptr = aux->data_ptr();
+    ldaux = aux->stride(0);
+  }
+  pda::gemm_fused(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias_ptr, out.data_ptr(), N, aux_ptr, ldaux, (int)M,
+                  (int)N, (int)K, epi, current_stream());
+  check_launch("gemm_fused");
+  return result;
+}
+
 // -------------------------------------------------------------- embedding --
 at::Tensor embedding_forward(const at::Tensor& ids, const at::Tensor& wte, const std::optional<at::Tensor>& wpe) {
   check_gpu(wte, "wte");
@@ -547,6 +602,9 @@ std::vector<at::Tensor> embedding_backward(const at::Tensor& ids, const at::Tens
 }
 
 void bind_ops(py::module_& m) {
+  m.def("gemm_fused_supported", &gemm_fused_supported);
+  m.def("gemm_fused", &gemm_fused, py::arg("x"), py::arg("w"), py::arg("bias") = py::none(), py::arg("epilogue") = "none",
+        py::arg("aux") = py::none());
   m.def("embedding_forward", &embedding_forward, py::arg("ids"), py::arg("wte"), py::arg("wpe") = py::none());
   m.def("embedding_backward", &embedding_backward, py::arg("ids"), py::arg("dout"), py::arg("vocab"), py::arg("need_wpe"),
         py::arg("wpe_rows") = 0, py::arg("dwte_out") = py::none(), py::arg("wte_accumulate") = false,

@@ -5,47 +5,15 @@
 // kernels recompute the activation from the saved pre-activation, so the
 // forward never has to keep tanh / sigmoid values.
 //
-// gelu_new is the activation every GPT-2 config selects through
-// ACT2FN[config.activation_function]
-// (reference: assignments/assignment1/model/my_gpt2.py:90,96).
+// The activation math lives in gelu_math.h (shared with the GEMM epilogues of gemm_fused.hip).
 #include "common.h"
+#include "gelu_math.h"
 #include "pda_kernels.h"
 
 namespace pda {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr float kSqrt2OverPi = 0.7978845608028654f;
-constexpr float kGeluC = 0.044715f;
-
-constexpr float kLog2e = 1.4426950408889634f;
-
-// 0.5 (1 + tanh(z)) = sigmoid(2z), so gelu_new(u) = u * sigmoid(2 sqrt(2/pi) (u + c u^3)).
-// sigmoid(x) = 1 / (1 + exp2(-x log2 e)) with the hardware exp2 and reciprocal (1 ulp each; the
-// result is rounded to bf16): nine VALU instructions per element where tanh through __expf and
-// an IEEE division took twenty-four and made these streaming kernels VALU-bound. exp2 overflow
-// (very negative x) gives 1 / inf = 0 and underflow gives 1, the correct limits.
-__device__ __forceinline__ float sigmoid_f(float x) {
-  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kLog2e * x));
-}
-
-__device__ __forceinline__ float gelu_f(float u) {
-  const float u2 = u * u;
-  // exp2 argument: -2 log2(e) sqrt(2/pi) (u + c u^3) = u * (a + b u^2)
-  constexpr float a = -2.f * kLog2e * kSqrt2OverPi, b = a * kGeluC;
-  return u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * (a + b * u2)));
-}
-
-// d/du [u s(u)] with s = sigmoid(2 inner(u)): s + u s (1 - s) 2 inner'(u),
-// inner'(u) = sqrt(2/pi) (1 + 3 c u^2).
-__device__ __forceinline__ float gelu_grad_f(float u) {
-  const float u2 = u * u;
-  constexpr float a = -2.f * kLog2e * kSqrt2OverPi, b = a * kGeluC;
-  const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * (a + b * u2)));
-  const float dinner2 = 2.f * kSqrt2OverPi + (6.f * kSqrt2OverPi * kGeluC) * u2;
-  return s + u * (s - s * s) * dinner2;
-}
-
 inline unsigned stream_grid(int64_t nvec) {
   int64_t blocks = ceil_div(nvec, kThreads);
   if (blocks > 2048) blocks = 2048;

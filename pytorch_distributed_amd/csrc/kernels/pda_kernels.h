@@ -131,6 +131,18 @@ void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, v
                   const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
                   bool bias_accumulate, hipStream_t stream);
 
+// ------------------------------------------------------------- Fused-epilogue GEMM --
+// out[M, N] = epilogue(X[M, K] . W[N, K]^T), bf16 operands with row strides in elements (multiples
+// of 8, 16-byte aligned bases), fp32 accumulation. K % 32 == 0, N % 8 == 0 (gemm_fused_supported).
+//   kEpiNone          out = acc
+//   kEpiBias          out = acc + bias[N]
+//   kEpiBiasGelu      out = u = acc + bias,  aux = gelu_new(u)           (aux: second output [M, N])
+//   kEpiMulGeluGrad   out = acc * gelu_new'(aux)                         (aux: input  [M, N])
+enum GemmEpilogue : int { kEpiNone = 0, kEpiBias = 1, kEpiBiasGelu = 2, kEpiMulGeluGrad = 3 };
+bool gemm_fused_supported(int M, int N, int K);
+void gemm_fused(const void* X, int64_t ldx, const void* W, int64_t ldw, const void* bias, void* out, int64_t ldo, void* aux,
+                int64_t ldaux, int M, int N, int K, int epilogue, hipStream_t stream);
+
 // ----------------------------------------------------------------- Embedding --
 // out[n, :] = wte[ids[n], :] (+ wpe[n mod T, :] when wpe != nullptr). d % (16 / sizeof(T)) == 0.
 void embedding_forward(DType dtype, const int64_t* ids, const void* wte, const void* wpe, void* out, int64_t n_tokens,

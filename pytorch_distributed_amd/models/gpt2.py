@@ -74,8 +74,8 @@ class MyGPT2MLP(nn.Module):
         self.dropout = nn.Dropout(p=config.resid_pdrop)
 
     def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True) -> torch.Tensor:
-        u = ops.linear(hidden_states, self.c_fc.weight, self.c_fc.bias)
-        out = ops.linear(ops.gelu_new(u), self.c_proj.weight, self.c_proj.bias)
+        # c_fc -> gelu_new -> c_proj with the activation applied in the GEMM epilogues on the GPU
+        out = ops.gelu_mlp(hidden_states, self.c_fc.weight, self.c_fc.bias, self.c_proj.weight, self.c_proj.bias)
         return self.dropout(out) if apply_dropout else out
 
 

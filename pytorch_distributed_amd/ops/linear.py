@@ -131,6 +131,35 @@ def _grad_target(param, sink):
     return target
 
 
+def weight_grads(dy2, x2, weight, bias, grad_sink, bias_sink, need_w: bool, need_b: bool):
+    """``(dW, db)`` of ``y = x W^T + b`` from ``dy2 [tokens, out]`` and ``x2 [tokens, in]``.
+
+    On the native path the kernel's slice-reduction pass writes (or adds) each gradient straight
+    into its target — the owner's flat buffer (gradient sink), or an existing ``.grad`` when
+    gradients are accumulated without a wrapper — and None is returned for that parameter: autograd
+    then gets None, its accumulator node still runs, so the owner's hook on it fires and counts the
+    parameter as ready."""
+    dw = db = None
+    if need_w and _native_wgrad_ok(dy2, x2):
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        w_target = _grad_target(weight, grad_sink)
+        b_target = _grad_target(bias, bias_sink) if need_b else None
+        w_out, w_acc = w_target if w_target is not None else (None, False)
+        b_out, b_acc = b_target if b_target is not None else (None, False)
+        dw_native, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), w_out, w_acc,
+                                                           b_out, b_acc)
+        dw = dw_native if w_target is None else None
+        if need_b and b_target is None:
+            db = db_native
+    else:
+        if need_w:
+            dw = torch.mm(dy2.t(), x2)
+        if need_b:
+            db = dy2.sum(0)
+    return dw, db
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -157,27 +186,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = input_grad_mm(dy2, weight).view(x.shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if need_w and _native_wgrad_ok(dy2, x2):
-            if not dy2.is_contiguous():
-                dy2 = dy2.contiguous()
-            # The kernel's slice-reduction pass writes (or adds) each gradient straight into its
-            # target: the owner's flat buffer (gradient sink), or an existing .grad when gradients
-            # are accumulated without a wrapper. Autograd then gets None for that parameter; its
-            # accumulator node still runs, so the owner's hook on it fires and counts it as ready.
-            w_target = _grad_target(weight, ctx.grad_sink)
-            b_target = _grad_target(ctx.bias, ctx.bias_sink) if need_b else None
-            w_out, w_acc = w_target if w_target is not None else (None, False)
-            b_out, b_acc = b_target if b_target is not None else (None, False)
-            dw_native, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), w_out, w_acc,
-                                                               b_out, b_acc)
-            dw = dw_native if w_target is None else None
-            if need_b and b_target is None:
-                db = db_native
-        else:
-            if need_w:
-                dw = torch.mm(dy2.t(), x2)
-            if need_b:
-                db = dy2.sum(0)
+        dw, db = weight_grads(dy2, x2, weight, ctx.bias, ctx.grad_sink, ctx.bias_sink, need_w, need_b)
         return dx, dw, db
 
 

@@ -1,0 +1,87 @@
+"""GPT-2 MLP (``c_fc -> gelu_new -> c_proj``) with the activation fused into the GEMMs.
+
+The reference runs the activation as five unfused element-wise ops between two ``nn.Linear`` calls
+(assignments/assignment1/model/my_gpt2.py:94-99). Here the activation never has a kernel of its
+own on the GPU (``csrc/kernels/gemm_fused.hip``):
+
+* forward: the ``c_fc`` GEMM adds the bias and writes both the pre-activation ``u`` (kept for the
+  backward) and ``gelu(u)`` (the input of ``c_proj``) from its accumulators;
+* backward: the input gradient of ``c_proj`` is formed on the transposed weight and multiplied by
+  ``gelu'(u)`` in the epilogue, producing ``du`` directly — the ``[tokens, 4d]`` gradient of the
+  activation output is never written.
+
+Weight and bias gradients use the native weight-gradient kernel with gradient sinks, exactly as in
+``ops.linear``.
+
+Status: OPT-IN (``PDA_FUSED_MLP=1``). Measured on MI355X at 32 K tokens, d = 1280
+(``tools/gemm_fused_probe.py``, ``profiles/r2/gemm_fused_probe.log``): the kernel's main loop runs at
+0.74 PFLOP/s where hipBLASLt's tuned algorithm reaches 1.37, and its register-direct epilogue
+(8-byte stores, 16 contiguous bytes per row and instruction) costs more than the stand-alone GELU
+kernel it replaces — 941 us fused against 457 us for library GEMM + GELU kernel. Until the kernel
+beats that pair, the default is the library GEMM with the stand-alone activation kernels (which run
+at the HBM roofline); the fused path stays available, tested, for further work on it.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import _ext
+from .activations import gelu_new
+from .linear import input_grad_mm, linear, planned_mm, weight_grads
+
+
+class _GeluMLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_fc, b_fc, w_proj, b_proj):
+        ext = _ext.require()
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        u, g = ext.gemm_fused(x2, w_fc, b_fc, "bias_gelu", None)
+        y = torch.empty(*x.shape[:-1], w_proj.shape[0], dtype=x.dtype, device=x.device)
+        planned_mm(g, w_proj, trans_b=True, bias=b_proj, out=y.view(-1, w_proj.shape[0]))
+        ctx.save_for_backward(x2, u, g, w_fc, w_proj)
+        ctx.x_shape = x.shape
+        ctx.params = (w_fc, b_fc, w_proj, b_proj)  # consulted for .grad / gradient sinks only
+        ctx.sinks = tuple(getattr(p, "_pda_grad_sink", None) for p in ctx.params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ext = _ext.require()
+        x2, u, g, w_fc, w_proj = ctx.saved_tensors
+        _, b_fc, _, b_proj = ctx.params
+        s_wfc, s_bfc, s_wproj, s_bproj = ctx.sinks
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dw_proj, db_proj = weight_grads(dy2, g, w_proj, b_proj, s_wproj, s_bproj, need[3], need[4])
+        # du = (dy . W_proj) * gelu'(u): contraction over W_proj's row index, so the kernel runs on the
+        # transposed weight (a few microseconds against a GEMM of hundreds)
+        (du,) = ext.gemm_fused(dy2, ext.transpose_2d(w_proj, 8), None, "mul_gelu_grad", u)
+        dw_fc, db_fc = weight_grads(du, x2, w_fc, b_fc, s_wfc, s_bfc, need[1], need[2])
+        dx = input_grad_mm(du, w_fc).view(ctx.x_shape) if need[0] else None
+        return dx, dw_fc, db_fc, dw_proj, db_proj
+
+
+def _fused_ok(x, w_fc, b_fc, w_proj, b_proj) -> bool:
+    if os.environ.get("PDA_FUSED_MLP", "0") != "1" or not _ext.use_hip(x):
+        return False
+    if x.dtype != torch.bfloat16 or b_fc is None or b_proj is None:
+        return False
+    tokens = x.numel() // x.shape[-1]
+    ext = _ext.require()
+    d, f = w_fc.shape[1], w_fc.shape[0]
+    return (w_proj.shape == (d, f) and w_fc.is_contiguous() and w_proj.is_contiguous()
+            and ext.gemm_fused_supported(tokens, f, d) and ext.gemm_fused_supported(tokens, f, w_proj.shape[0])
+            and d % 8 == 0)
+
+
+def gelu_mlp(x: torch.Tensor, w_fc: torch.Tensor, b_fc, w_proj: torch.Tensor, b_proj) -> torch.Tensor:
+    """``linear(gelu_new(linear(x, w_fc, b_fc)), w_proj, b_proj)``."""
+    if _fused_ok(x, w_fc, b_fc, w_proj, b_proj):
+        return _GeluMLPFn.apply(x, w_fc, b_fc, w_proj, b_proj)
+    return linear(gelu_new(linear(x, w_fc, b_fc)), w_proj, b_proj)

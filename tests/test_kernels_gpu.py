@@ -503,3 +503,38 @@ def test_embedding_backward_accumulates_into_an_existing_gradient():
     ops.embedding(ids, wte).backward(dout)
     ref = existing.float().index_add(0, ids.reshape(-1), dout.reshape(-1, d).float())
     assert rel_err(wte.grad, ref) < 6e-3
+
+
+# ------------------------------------------------------------------ fused-epilogue GEMM
+def _gelu_new_f32(u):
+    return 0.5 * u * (1.0 + torch.tanh(0.7978845608028654 * (u + 0.044715 * u ** 3)))
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (1000, 776, 96), (4096, 5120, 1280), (300, 3072, 768), (2048, 6400, 1600)])
+def test_gemm_fused_epilogues_match_fp32_reference(M, N, K):
+    """out = epilogue(x @ w.T) for the four epilogues, against fp32 PyTorch on the same bf16 inputs;
+    shapes include partial tiles in both dimensions and every GPT-2 width."""
+    ext = _ext.require()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+    ref = x.float() @ w.float().t()
+    (plain,) = ext.gemm_fused(x, w, None, "none", None)
+    assert rel_err(plain, ref) < 4e-3
+    (biased,) = ext.gemm_fused(x, w, b, "bias", None)
+    assert rel_err(biased, ref + b.float()) < 4e-3
+    u, act = ext.gemm_fused(x, w, b, "bias_gelu", None)
+    assert torch.equal(u, biased)
+    assert rel_err(act, _gelu_new_f32(u.float())) < 4e-3  # the activation of the stored (rounded) pre-activation
+    pre = (torch.randn(M, N, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    (dgel,) = ext.gemm_fused(x, w, None, "mul_gelu_grad", pre)
+    pf = pre.float().requires_grad_(True)
+    _gelu_new_f32(pf).sum().backward()
+    assert rel_err(dgel, ref * pf.grad) < 5e-3
+    # strided operands (a column slice of a wider matrix) and an aux with a row pitch
+    wide = torch.randn(M, K + 64, generator=g).to(torch.bfloat16).to(DEV)
+    xs = wide[:, 32:32 + K] if K % 8 == 0 else wide[:, :K]
+    if xs.data_ptr() % 16 == 0:
+        (strided,) = ext.gemm_fused(xs, w, None, "none", None)
+        assert rel_err(strided, xs.float() @ w.float().t()) < 4e-3

@@ -182,3 +182,27 @@ def test_graphed_train_step_at_the_gpt2_vocabulary_with_fresh_tokens_every_repla
     torch.cuda.synchronize()
     assert rel_err(ref.transformer.wte.weight, mod.transformer.wte.weight) < 2e-2
     assert rel_err(ref.transformer.h[0].mlp.c_fc.weight, mod.transformer.h[0].mlp.c_fc.weight) < 2e-2
+
+
+def test_fused_mlp_path_matches_the_separate_ops(monkeypatch):
+    """PDA_FUSED_MLP=1 (activation applied in the GEMM epilogues) against the default three-op MLP:
+    same output and same gradients for input, weights and biases."""
+    from pytorch_distributed_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    d, tokens = 256, 640
+    x = torch.randn(2, tokens // 2, d, generator=g).to(torch.bfloat16).to(DEV)
+    params = [(torch.randn(4 * d, d, generator=g) * d ** -0.5), torch.randn(4 * d, generator=g) * 0.1,
+              (torch.randn(d, 4 * d, generator=g) * (4 * d) ** -0.5), torch.randn(d, generator=g) * 0.1]
+    dy = torch.randn(2, tokens // 2, d, generator=g).to(torch.bfloat16).to(DEV)
+
+    def run(flag):
+        monkeypatch.setenv("PDA_FUSED_MLP", flag)
+        xs = x.clone().requires_grad_(True)
+        ps = [p.to(torch.bfloat16).to(DEV).requires_grad_(True) for p in params]
+        out = ops.gelu_mlp(xs, *ps)
+        out.backward(dy)
+        return [out, xs.grad] + [p.grad for p in ps]
+
+    for a, b in zip(run("1"), run("0")):
+        assert rel_err(a, b) < 1e-2
