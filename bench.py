@@ -141,23 +141,23 @@ def main():
         raise SystemExit("--batch-per-gpu must be a multiple of --micro-batch")
     accum = args.batch_per_gpu // args.micro_batch
 
-    policy = None
-    if distributed:
-        comm.init_distributed(backend="rccl" if args.comm == "native" else "c10d", timeout_s=300.0)
-        if world > 1 and not args.no_comm_autotune:
-            policy = autotune.tune(device=device, verbose=True)
-
     cfg = get_config(args.model).without_dropout()
     if args.dropout > 0 and hasattr(cfg, "attn_pdrop"):
         cfg.attn_pdrop = cfg.resid_pdrop = cfg.embd_pdrop = args.dropout
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     is_llama = hasattr(cfg, "intermediate_size")
     cls = LlamaForCausalLM if is_llama else MyGPT2LMHeadModel
-    on_gpu = args.init_device == "gpu"
-    if args.init_device == "auto":
-        with init_on_device("meta"):
-            on_gpu = sum(p.numel() for p in cls(cfg).parameters()) > 1e9
+    with init_on_device("meta"):
+        n_params = sum(p.numel() for p in cls(cfg).parameters())
+    on_gpu = args.init_device == "gpu" or (args.init_device == "auto" and n_params > 1e9)
     fpt = model_flops_per_token(_cfg_holder(cfg), args.seq_len)
+
+    policy = None
+    if distributed:
+        comm.init_distributed(backend="rccl" if args.comm == "native" else "c10d", timeout_s=300.0)
+        if world > 1 and not args.no_comm_autotune:
+            policy = autotune.tune(device=device, total_grad_bytes=n_params * (2 if args.dtype == "bf16" else 4),
+                                   verbose=True)
 
     def build_model():
         import contextlib

@@ -170,6 +170,7 @@ class RecordingCommunicator final : public Communicator {
     return inner_->broadcast(t, root, q);
   }
   void barrier() override { inner_->barrier(); }
+  void close() override { inner_->close(); }
   void abort() override { inner_->abort(); }
   std::vector<std::string> exchange(const std::string& mine) override { return inner_->exchange(mine); }
 

@@ -76,6 +76,7 @@ void bind_comm(py::module_& m) {
           py::arg("tensor"), py::arg("root") = 0, py::arg("queue") = 0, py::call_guard<py::gil_scoped_release>())
       .def("barrier", &Communicator::barrier, py::call_guard<py::gil_scoped_release>())
       .def("abort", &Communicator::abort, py::call_guard<py::gil_scoped_release>())
+      .def("close", &Communicator::close, py::call_guard<py::gil_scoped_release>())
       .def(
           "exchange",
           [](Communicator& c, const py::bytes& mine) {

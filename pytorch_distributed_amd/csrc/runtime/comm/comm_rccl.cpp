@@ -183,25 +183,32 @@ class RcclCommunicator final : public Communicator {
     if (use_watchdog_) watchdog_ = std::thread([this] { watch(); });
   }
 
-  ~RcclCommunicator() override {
+  ~RcclCommunicator() override { close(); }
+
+  void close() override {
     {
       std::lock_guard<std::mutex> lock(watch_mu_);
+      if (closed_) return;
+      closed_ = true;
       stop_ = true;
     }
     watch_cv_.notify_all();
     if (watchdog_.joinable()) watchdog_.join();
+    std::lock_guard<std::mutex> lock(mu_);
     if (comm_ != nullptr) {
-      if (aborted_->load()) {
-        // already torn down by abort()
-      } else {
+      if (!aborted_->load()) {  // abort() already tore the library communicator down
         (void)hipSetDevice(device_);
-        for (auto s : streams_) (void)hipStreamSynchronize(s);
+        for (auto s : streams_)
+          if (s) (void)hipStreamSynchronize(s);
         (void)ncclCommDestroy(comm_);
       }
       comm_ = nullptr;
     }
-    for (auto s : streams_)
+    for (auto& s : streams_) {
       if (s) (void)hipStreamDestroy(s);
+      s = nullptr;
+    }
+    watched_.clear();
   }
 
   int rank() const override { return rank_; }
@@ -269,6 +276,7 @@ class RcclCommunicator final : public Communicator {
   std::shared_ptr<Work> issue(Queue q, std::vector<at::Tensor> keep, const char* what, F&& launch) {
     TORCH_CHECK(!aborted_->load(), "communicator was aborted (a collective timed out or a peer failed)");
     std::lock_guard<std::mutex> lock(mu_);  // RCCL calls on one communicator are serialised
+    TORCH_CHECK(comm_ != nullptr, "communicator is closed");
     int prev = 0;
     PDA_HIP(hipGetDevice(&prev));
     if (prev != device_) PDA_HIP(hipSetDevice(device_));
@@ -339,6 +347,7 @@ class RcclCommunicator final : public Communicator {
   std::condition_variable watch_cv_;
   std::deque<Watched> watched_;
   bool stop_ = false;
+  bool closed_ = false;
   bool use_watchdog_ = true;
 };
 

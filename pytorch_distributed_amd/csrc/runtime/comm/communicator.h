@@ -73,6 +73,10 @@ class Communicator {
   virtual std::shared_ptr<Work> reduce_scatter(const at::Tensor& out, const at::Tensor& in, RedOp op, Queue q) = 0;
   virtual std::shared_ptr<Work> broadcast(const at::Tensor& t, int root, Queue q) = 0;
   virtual void barrier() = 0;  // host-side rendezvous of all ranks (does not drain GPU streams)
+  // Orderly shutdown: waits for outstanding work, releases the library communicator and the
+  // streams; later collectives raise. Called by parallel.shutdown() so that nothing is torn down
+  // from a destructor at interpreter exit, after the HIP runtime may already be gone.
+  virtual void close() {}
   // Tears the communicator down without waiting for outstanding work (after a timeout / fault).
   virtual void abort() = 0;
   virtual bool aborted() const { return false; }

@@ -175,6 +175,10 @@ StoreServer::StoreServer(const std::string& host, int base_port, int scan, std::
 }
 
 StoreServer::~StoreServer() {
+  // Ranks leave a job at slightly different times: a peer may still be waiting for the reply to its
+  // last barrier when rank 0 is already shutting down. Keep serving until every other client has
+  // closed its connection (bounded, so a crashed peer cannot hold rank 0 for ever).
+  for (int i = 0; i < 100 && open_clients_.load() > 0; ++i) ::usleep(100 * 1000);
   stop_ = true;
   char b = 1;
   (void)!::write(wake_fd_[1], &b, 1);
@@ -287,6 +291,7 @@ void StoreServer::loop() {
         Client c;
         c.fd = fd;
         clients_[fd] = std::move(c);
+        ++open_clients_;
       }
     }
     for (size_t i = 2; i < fds.size(); ++i) {
@@ -315,6 +320,7 @@ void StoreServer::loop() {
         }
         ::close(fd);
         clients_.erase(it);
+        --open_clients_;
       }
     }
   }

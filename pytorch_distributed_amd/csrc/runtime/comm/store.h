@@ -58,6 +58,7 @@ class StoreServer {
   int listen_fd_ = -1, wake_fd_[2] = {-1, -1}, port_ = 0;
   std::thread thread_;
   std::atomic<bool> stop_{false};
+  std::atomic<int> open_clients_{0};  // connections currently open (rank 0's own included)
   std::map<std::string, std::string> data_;
   std::map<std::string, std::vector<int>> waiters_;
   std::map<int, Client> clients_;
@@ -82,6 +83,8 @@ class StoreClient {
 
 // Both ends of the rendezvous for one process.
 struct Rendezvous {
+  // Declaration order matters: members are destroyed in reverse, so rank 0's own client closes its
+  // connection before the server starts waiting for the remaining (peer) connections to close.
   std::unique_ptr<StoreServer> server;  // rank 0 only
   std::unique_ptr<StoreClient> client;  // nullptr when world == 1
   int rank = 0, world = 1;

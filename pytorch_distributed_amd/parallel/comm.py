@@ -115,8 +115,10 @@ def set_communicator(comm, device=None) -> None:
 def shutdown() -> None:
     """Counterpart of the reference's ``dist.destroy_process_group()`` (train_ddp.py:146)."""
     global _COMM, _DEVICE, _OWNS_C10D
-    if _COMM is not None and _COMM.on_gpu and torch.cuda.is_available():
-        torch.cuda.synchronize()
+    if _COMM is not None:
+        if _COMM.on_gpu and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        _COMM.close()  # wrappers may still hold references; the library communicator goes now
     _COMM = None
     _DEVICE = None
     if _OWNS_C10D:
