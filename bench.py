@@ -64,7 +64,9 @@ def parse_args(argv=None):
                     help="construct the model on the host (then move) or directly on the GPU; auto = GPU above 1e9 parameters")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="attention / residual / embedding dropout probability (GPT-2 configurations; 0 = off)")
-    ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="selective")
+    ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="none",
+                    help="none keeps every activation (fastest, default here); selective rebuilds element-wise "
+                         "activations in backward (the reference's default policy); full re-runs each block")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
     ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",

@@ -11,6 +11,7 @@ void bind_reducer(py::module_& m);
 void bind_fsdp(py::module_& m);
 void bind_loader(py::module_& m);
 void bind_tracer(py::module_& m);
+void bind_recompute(py::module_& m);
 namespace pda {
 void bind_gemm(py::module_& m);
 }
@@ -24,5 +25,6 @@ PYBIND11_MODULE(_C, m) {
   bind_fsdp(m);
   bind_loader(m);
   bind_tracer(m);
+  bind_recompute(m);
   pda::bind_gemm(m);
 }

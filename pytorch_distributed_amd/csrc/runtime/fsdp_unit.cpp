@@ -41,6 +41,7 @@
 #include "comm/communicator.h"
 #include "comm_debug.h"
 #include "range_tracer.h"
+#include "recompute.h"
 
 #include <memory>
 #include <mutex>
@@ -508,8 +509,12 @@ class ShardedRuntime {
   void begin_pass() {
     in_pass_ = true;
     for (auto& u : units_) u->reset_pass();
-    torch::autograd::Engine::get_default_engine().queue_callback([this, alive = alive_] {
-      if (*alive) this->finish_pass();
+    // (through recompute::defer: inside a recomputed block the current graph task is the block's)
+    pda::recompute::defer([this, alive = alive_] {
+      if (!*alive) return;
+      torch::autograd::Engine::get_default_engine().queue_callback([this, alive] {
+        if (*alive) this->finish_pass();
+      });
     });
   }
 

@@ -38,6 +38,7 @@
 #include "comm/communicator.h"
 #include "comm_debug.h"
 #include "range_tracer.h"
+#include "recompute.h"
 
 #include <memory>
 #include <mutex>
@@ -224,7 +225,9 @@ class GradReducer {
       b.work.clear();
     }
     ready_.assign(params_.size(), false);
-    torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finish_pass(); });
+    // (through recompute::defer: inside a recomputed block the current graph task is the block's)
+    pda::recompute::defer(
+        [this] { torch::autograd::Engine::get_default_engine().queue_callback([this] { this->finish_pass(); }); });
   }
 
   void on_grad_ready(size_t idx) {

@@ -19,10 +19,18 @@ What is different underneath:
   LayerNorm kernel also performs the preceding residual add;
 * ``forward(input_ids, targets)`` returns the mean cross-entropy through the fused
   LM-head + softmax-CE op, never materialising fp32 logits;
-* activation memory follows the reference's selective-checkpoint policy structurally:
-  the fused ops keep matmul outputs plus per-row statistics and recompute the cheap
-  element-wise work in backward. ``activation_checkpoint="full"`` additionally
-  recomputes whole blocks.
+* activation memory, ``activation_checkpoint=``:
+
+  - ``"selective"`` (default, the reference's policy, my_gpt2.py:176-196): GEMM and attention
+    outputs plus per-row statistics are kept; everything element-wise — both LayerNorm outputs
+    and ``gelu(u)`` — is rebuilt in backward by the op that needs it (``ops.regen``), without
+    re-running the block;
+  - ``"none"``: additionally keeps those three activations (no recomputation at all; what the
+    throughput benchmark uses, 288 GB of HBM make the 4 % recompute cost unnecessary);
+  - ``"full"``: keeps only each block's input and re-runs the block inside backward
+    (``utils.recompute``).
+
+  ``enable_activation_checkpoint=False`` is the reference's switch and equals ``"none"``.
 """
 from __future__ import annotations
 
@@ -30,9 +38,10 @@ from typing import Optional, Tuple, Union
 
 import torch
 from torch import nn
-from torch.utils.checkpoint import checkpoint
 
 from .. import ops
+from ..ops.regen import NormRegen
+from ..utils.recompute import recompute
 from .config import GPT2Config, get_config, normalize_gpt2_config
 
 
@@ -50,11 +59,12 @@ class MyGPT2Attention(nn.Module):
         self.attn_pdrop = float(config.attn_pdrop)
         self.resid_dropout = nn.Dropout(p=config.resid_pdrop)
 
-    def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True, input_regen=None) -> torch.Tensor:
         """``apply_dropout=False``: the caller applies ``resid_dropout`` itself (the block fuses it
-        into the next LayerNorm kernel)."""
+        into the next LayerNorm kernel). ``input_regen``: recipe that rebuilds ``hidden_states`` in
+        backward (``ops.regen``), so that ``c_attn`` does not keep it."""
         # [B, T, 3d], consumed in place by the attention kernel
-        qkv = ops.linear(hidden_states, self.c_attn.weight, self.c_attn.bias)
+        qkv = ops.linear(hidden_states, self.c_attn.weight, self.c_attn.bias, regen=input_regen)
         ctx = ops.causal_attention(qkv, self.num_heads, dropout_p=self.attn_pdrop, training=self.training)
         out = ops.linear(ctx, self.c_proj.weight, self.c_proj.bias)
         return self.resid_dropout(out) if apply_dropout else out
@@ -73,9 +83,12 @@ class MyGPT2MLP(nn.Module):
         self.c_proj = nn.Linear(4 * self.embed_dim, self.embed_dim, bias=True)
         self.dropout = nn.Dropout(p=config.resid_pdrop)
 
-    def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True) -> torch.Tensor:
-        # c_fc -> gelu_new -> c_proj with the activation applied in the GEMM epilogues on the GPU
-        out = ops.gelu_mlp(hidden_states, self.c_fc.weight, self.c_fc.bias, self.c_proj.weight, self.c_proj.bias)
+    def forward(self, hidden_states: torch.Tensor, apply_dropout: bool = True, input_regen=None,
+                regen_activation: bool = False) -> torch.Tensor:
+        """``input_regen`` as in :class:`MyGPT2Attention`; ``regen_activation``: ``c_proj`` rebuilds
+        ``gelu(u)`` from the kept ``u`` in backward instead of keeping it."""
+        out = ops.gelu_mlp(hidden_states, self.c_fc.weight, self.c_fc.bias, self.c_proj.weight, self.c_proj.bias,
+                           input_regen=input_regen, regen_activation=regen_activation)
         return self.dropout(out) if apply_dropout else out
 
 
@@ -99,13 +112,18 @@ class MyGPT2Block(nn.Module):
         self.ln_2 = nn.LayerNorm(self.embed_dim, eps=config.layer_norm_epsilon)
         self.mlp = MyGPT2MLP(config)
 
-    def _run(self, delta, residual, delta_pdrop: float) -> Tuple[torch.Tensor, torch.Tensor]:
-        y, h = ops.fused_add_layer_norm(delta, residual, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps,
+    def _run(self, delta, residual, delta_pdrop: float, regen: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        ln = self.ln_1
+        y, h = ops.fused_add_layer_norm(delta, residual, ln.weight, ln.bias, ln.eps,
                                         dropout_p=delta_pdrop, training=self.training)
-        a = self.attn(y, apply_dropout=False)
-        y, h = ops.fused_add_layer_norm(a, h, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps,
+        a = self.attn(y, apply_dropout=False,
+                      input_regen=NormRegen(h, ln.weight, ln.bias, ln.eps) if regen else None)
+        ln = self.ln_2
+        y, h = ops.fused_add_layer_norm(a, h, ln.weight, ln.bias, ln.eps,
                                         dropout_p=self.attn.resid_dropout.p, training=self.training)
-        return self.mlp(y, apply_dropout=False), h
+        out = self.mlp(y, apply_dropout=False, regen_activation=regen,
+                       input_regen=NormRegen(h, ln.weight, ln.bias, ln.eps) if regen else None)
+        return out, h
 
     @property
     def out_pdrop(self) -> float:
@@ -113,8 +131,10 @@ class MyGPT2Block(nn.Module):
         return self.mlp.dropout.p
 
     def forward(self, hidden_state: torch.Tensor, residual: Optional[torch.Tensor] = None, *,
-                fused: bool = False, delta_pdrop: float = 0.0):
-        out, h = self._run(hidden_state, residual, delta_pdrop)
+                fused: bool = False, delta_pdrop: float = 0.0, regen: bool = False):
+        """``regen``: element-wise activations are rebuilt in backward instead of kept (the
+        ``"selective"`` policy of :class:`MyGPT2Model`)."""
+        out, h = self._run(hidden_state, residual, delta_pdrop, regen and torch.is_grad_enabled())
         if fused:
             return out, h
         return self.mlp.dropout(out) + h
@@ -147,14 +167,13 @@ class MyGPT2Model(nn.Module):
         delta = ops.token_position_embedding(input_ids, self.wte.weight, self.wpe.weight)
         pdrop = self.drop.p
         residual = None
-        full_recompute = (self.enable_activation_checkpoint and self.training
-                          and self.activation_checkpoint == "full")
+        mode = self.activation_checkpoint if self.enable_activation_checkpoint else "none"
+        full_recompute = mode == "full" and self.training and torch.is_grad_enabled()
         for block in self.h:
             if full_recompute:
-                delta, residual = checkpoint(block, delta, residual, fused=True, delta_pdrop=pdrop,
-                                             use_reentrant=False)
+                delta, residual = recompute(block, delta, residual, fused=True, delta_pdrop=pdrop)
             else:
-                delta, residual = block(delta, residual, fused=True, delta_pdrop=pdrop)
+                delta, residual = block(delta, residual, fused=True, delta_pdrop=pdrop, regen=mode == "selective")
             pdrop = block.out_pdrop
         out, _ = ops.fused_add_layer_norm(delta, residual, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps,
                                           dropout_p=pdrop, training=self.training)

@@ -16,9 +16,10 @@ from typing import Optional
 
 import torch
 from torch import nn
-from torch.utils.checkpoint import checkpoint
 
 from .. import _ext, ops
+from ..ops.regen import NormRegen, SwigluRegen
+from ..utils.recompute import recompute
 from .config import LlamaConfig, get_config
 
 
@@ -98,8 +99,8 @@ class LlamaAttention(nn.Module):
         self.wqkv = nn.Linear(config.n_embd, 3 * config.n_embd, bias=False)
         self.c_proj = nn.Linear(config.n_embd, config.n_embd, bias=False)
 
-    def forward(self, x, cos, sin):
-        qkv = _RopePacked.apply(ops.linear(x, self.wqkv.weight), cos, sin, self.num_heads)
+    def forward(self, x, cos, sin, input_regen=None):
+        qkv = _RopePacked.apply(ops.linear(x, self.wqkv.weight, regen=input_regen), cos, sin, self.num_heads)
         return ops.linear(ops.causal_attention(qkv, self.num_heads), self.c_proj.weight)
 
 
@@ -109,8 +110,9 @@ class LlamaMLP(nn.Module):
         self.gate_up = nn.Linear(config.n_embd, 2 * config.intermediate_size, bias=False)
         self.down = nn.Linear(config.intermediate_size, config.n_embd, bias=False)
 
-    def forward(self, x):
-        return ops.linear(ops.swiglu(ops.linear(x, self.gate_up.weight)), self.down.weight)
+    def forward(self, x, input_regen=None, regen_activation: bool = False):
+        gu = ops.linear(x, self.gate_up.weight, regen=input_regen)
+        return ops.linear(ops.swiglu(gu), self.down.weight, regen=SwigluRegen(gu) if regen_activation else None)
 
 
 class LlamaBlock(nn.Module):
@@ -122,12 +124,18 @@ class LlamaBlock(nn.Module):
         self.mlp = LlamaMLP(config)
         self.rope = None  # (cos, sin) shared tables, set by the trunk
 
-    def forward(self, hidden, residual=None, *, fused: bool = False):
+    def forward(self, hidden, residual=None, *, fused: bool = False, regen: bool = False):
+        """``regen``: the RMSNorm outputs and the SwiGLU output are rebuilt in backward instead of
+        kept (``activation_checkpoint="selective"``)."""
+        regen = regen and torch.is_grad_enabled()
         cos, sin = self.rope()
-        y, h = ops.fused_add_rms_norm(hidden, residual, self.ln_1.weight, self.ln_1.eps)
-        a = self.attn(y, cos, sin)
-        y, h = ops.fused_add_rms_norm(a, h, self.ln_2.weight, self.ln_2.eps)
-        out = self.mlp(y)
+        ln = self.ln_1
+        y, h = ops.fused_add_rms_norm(hidden, residual, ln.weight, ln.eps)
+        a = self.attn(y, cos, sin, input_regen=NormRegen(h, ln.weight, None, ln.eps, rms=True) if regen else None)
+        ln = self.ln_2
+        y, h = ops.fused_add_rms_norm(a, h, ln.weight, ln.eps)
+        out = self.mlp(y, regen_activation=regen,
+                       input_regen=NormRegen(h, ln.weight, None, ln.eps, rms=True) if regen else None)
         return (out, h) if fused else out + h
 
 
@@ -155,12 +163,13 @@ class LlamaModel(nn.Module):
             self._rope_cache = rope_tables(self.config.n_ctx, self.config.head_dim, self.config.rope_theta,
                                            input_ids.device)
         delta, residual = ops.embedding(input_ids, self.wte.weight), None
-        full = self.activation_checkpoint == "full" and self.training
+        mode = self.activation_checkpoint
+        full = mode == "full" and self.training and torch.is_grad_enabled()
         for block in self.h:
             if full:
-                delta, residual = checkpoint(block, delta, residual, fused=True, use_reentrant=False)
+                delta, residual = recompute(block, delta, residual, fused=True)
             else:
-                delta, residual = block(delta, residual, fused=True)
+                delta, residual = block(delta, residual, fused=True, regen=mode == "selective")
         out, _ = ops.fused_add_rms_norm(delta, residual, self.ln_f.weight, self.ln_f.eps)
         return out
 

@@ -162,8 +162,16 @@ def weight_grads(dy2, x2, weight, bias, grad_sink, bias_sink, need_w: bool, need
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, regen=None):
+        # With a recipe the input is rebuilt in backward from tensors its producer keeps anyway
+        # (ops.regen); otherwise the input itself is kept.
+        ctx.regen = None if regen is None else regen.recipe()
+        ctx.x_shape = x.shape
+        if regen is None:
+            ctx.save_for_backward(weight, x)
+        else:
+            ctx.regen_none = tuple(t is None for t in regen.tensors)
+            ctx.save_for_backward(weight, *[t for t in regen.tensors if t is not None])
         ctx.has_bias = bias is not None
         # Gradient sink: a sharding / reducing wrapper that owns a flat gradient buffer tags the
         # weight with a callable returning (slice_of_flat_buffer, accumulate).
@@ -179,24 +187,35 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        weight, *kept = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = input_grad_mm(dy2, weight).view(x.shape)
+            dx = input_grad_mm(dy2, weight).view(ctx.x_shape)
         need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dw, db = weight_grads(dy2, x2, weight, ctx.bias, ctx.grad_sink, ctx.bias_sink, need_w, need_b)
-        return dx, dw, db
+        if need_w or need_b:
+            if ctx.regen is None:
+                x = kept[0]
+            else:
+                it = iter(kept)
+                x = ctx.regen.rebuild(*[None if missing else next(it) for missing in ctx.regen_none])
+            x2 = x.reshape(-1, x.shape[-1])
+            dw, db = weight_grads(dy2, x2, weight, ctx.bias, ctx.grad_sink, ctx.bias_sink, need_w, need_b)
+        return dx, dw, db, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """``x @ weight.T + bias`` (``torch.nn.functional.linear`` semantics)."""
+def linear(x: torch.Tensor, weight: torch.Tensor, bias=None, regen=None) -> torch.Tensor:
+    """``x @ weight.T + bias`` (``torch.nn.functional.linear`` semantics).
+
+    ``regen`` (an :class:`ops.regen.Regen`) says how to rebuild ``x`` in backward from tensors that
+    are kept anyway; with it ``x`` is not saved. It has to describe exactly ``x``."""
     if _ext.use_hip(x):
         if x.dtype == torch.bfloat16:
-            return _LinearFn.apply(x, weight, bias)
+            return _LinearFn.apply(x, weight, bias, regen)
         if x.dtype == torch.float32:  # fp32 storage: bf16 MFMA inputs, fp32 accumulation, widened result
-            lo = torch.bfloat16
+            lo = torch.bfloat16  # (the bf16 copy of the input is kept; a recipe would rebuild the fp32 one)
             return _LinearFn.apply(x.to(lo), weight.to(lo), None if bias is None else bias.to(lo)).to(torch.float32)
         raise NotImplementedError(f"linear on the GPU: dtype {x.dtype} has no kernel (bf16, or fp32 through bf16 MFMA inputs)")
+    if regen is not None and torch.is_grad_enabled():
+        return _LinearFn.apply(x, weight, bias, regen)  # same autograd node on the CPU, torch matmuls inside
     return F.linear(x, weight, bias)

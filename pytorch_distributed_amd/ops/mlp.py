@@ -30,6 +30,7 @@ import torch
 from .. import _ext
 from .activations import gelu_new
 from .linear import input_grad_mm, linear, planned_mm, weight_grads
+from .regen import GeluRegen
 
 
 class _GeluMLPFn(torch.autograd.Function):
@@ -80,8 +81,14 @@ def _fused_ok(x, w_fc, b_fc, w_proj, b_proj) -> bool:
             and d % 8 == 0)
 
 
-def gelu_mlp(x: torch.Tensor, w_fc: torch.Tensor, b_fc, w_proj: torch.Tensor, b_proj) -> torch.Tensor:
-    """``linear(gelu_new(linear(x, w_fc, b_fc)), w_proj, b_proj)``."""
-    if _fused_ok(x, w_fc, b_fc, w_proj, b_proj):
+def gelu_mlp(x: torch.Tensor, w_fc: torch.Tensor, b_fc, w_proj: torch.Tensor, b_proj, *, input_regen=None,
+             regen_activation: bool = False) -> torch.Tensor:
+    """``linear(gelu_new(linear(x, w_fc, b_fc)), w_proj, b_proj)``.
+
+    ``input_regen``: recipe rebuilding ``x`` in backward (``ops.regen``), so ``c_fc`` does not keep
+    it; ``regen_activation``: ``c_proj`` rebuilds ``gelu(u)`` from the kept ``u`` instead of keeping
+    it. The fused-epilogue path keeps all three tensors and is skipped when either is asked for."""
+    if input_regen is None and not regen_activation and _fused_ok(x, w_fc, b_fc, w_proj, b_proj):
         return _GeluMLPFn.apply(x, w_fc, b_fc, w_proj, b_proj)
-    return linear(gelu_new(linear(x, w_fc, b_fc)), w_proj, b_proj)
+    u = linear(x, w_fc, b_fc, regen=input_regen)
+    return linear(gelu_new(u), w_proj, b_proj, regen=GeluRegen(u) if regen_activation else None)

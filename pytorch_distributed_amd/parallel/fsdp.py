@@ -283,17 +283,17 @@ class _BlockGroup(nn.Module):
         super().__init__()
         self.blocks = nn.ModuleList(blocks)
 
-    def forward(self, hidden, residual=None, *, fused: bool = False, delta_pdrop: float = 0.0):
+    def forward(self, hidden, residual=None, *, fused: bool = False, delta_pdrop: float = 0.0, regen: bool = False):
         if not fused:
             for b in self.blocks:
                 hidden = b(hidden)
             return hidden
         for b in self.blocks:
             if hasattr(b, "out_pdrop"):  # blocks whose pending output dropout the next LayerNorm applies
-                hidden, residual = b(hidden, residual, fused=True, delta_pdrop=delta_pdrop)
+                hidden, residual = b(hidden, residual, fused=True, delta_pdrop=delta_pdrop, regen=regen)
                 delta_pdrop = b.out_pdrop
             else:
-                hidden, residual = b(hidden, residual, fused=True)
+                hidden, residual = b(hidden, residual, fused=True, regen=regen)
         return hidden, residual
 
     @property

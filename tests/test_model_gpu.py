@@ -150,6 +150,41 @@ def test_full_recompute_reproduces_dropout_masks():
         assert rel_err(grads[1][1][n], g) < 1e-3, n
 
 
+def test_selective_policy_is_bit_identical_and_keeps_less_memory():
+    """"selective" rebuilds both LayerNorm outputs and gelu(u) in backward with the kernels that
+    produced them: losses and gradients equal those of the keep-everything run bit for bit, and the
+    peak of allocated memory over forward + backward drops by about 6d of the 22d elements a block
+    keeps per token."""
+    cfg = get_config("gpt2", n_layer=4).without_dropout()
+    torch.manual_seed(3)
+    base = MyGPT2LMHeadModel(cfg, activation_checkpoint="none").to(device=DEV, dtype=torch.bfloat16)
+    ids = torch.randint(0, cfg.vocab_size, (8, 513), device=DEV)
+    results, peaks = {}, {}
+    for mode in ("none", "selective", "full"):
+        model = MyGPT2LMHeadModel(cfg, activation_checkpoint=mode).to(device=DEV, dtype=torch.bfloat16)
+        model.load_state_dict(base.state_dict())
+        model.train()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        loss = model(ids[:, :-1], ids[:, 1:])
+        at_loss = torch.cuda.memory_allocated() - before
+        loss.backward()
+        torch.cuda.synchronize()
+        peaks[mode] = at_loss
+        results[mode] = (loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+        del model, loss
+    for mode in ("selective", "full"):
+        assert torch.equal(results[mode][0], results["none"][0]), mode
+        for n, g in results["none"][1].items():
+            assert torch.equal(results[mode][1][n], g), (mode, n)
+    tokens, d = 8 * 512, cfg.n_embd
+    saved = peaks["none"] - peaks["selective"]
+    expect = cfg.n_layer * tokens * 6 * d * 2
+    assert 0.9 * expect <= saved <= 1.1 * expect, (peaks, expect)
+    assert peaks["full"] < 0.5 * peaks["selective"], peaks
+
+
 def test_graphed_train_step_at_the_gpt2_vocabulary_with_fresh_tokens_every_replay():
     """Whole-step HIP-graph replay at the size class where a replay once faulted: GPT-2 vocabulary
     (50257), 4096 tokens per micro-batch, 2 micro-batches, token ids that change on every replay.
