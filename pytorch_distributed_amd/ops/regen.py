@@ -13,9 +13,9 @@ my_gpt2.py:176-196, built on ``torch.utils.checkpoint`` with a per-op policy) â€
 data carried by the consuming op rather than as a re-execution of the block under a policy: no
 second pass over the Python forward, no saved-tensor hooks, and the GEMMs are never re-run.
 
-Per GPT-2 block and token, what stays resident in bf16 drops from ``22 d`` elements (residual x2,
-LayerNorm outputs x2, QKV 3d, attention output, ``u`` 4d, ``gelu(u)`` 4d, plus projections'
-outputs) to ``16 d``; the price is two LayerNorm and one GELU kernel per block in backward
+Per GPT-2 block and token, what stays resident in bf16 drops from ``16 d`` elements (residual
+stream x2, QKV 3d, attention output, ``u`` 4d, and LayerNorm outputs x2, ``gelu(u)`` 4d) to
+``10 d``; the price is two LayerNorm and one GELU kernel per block in backward
 (about 4 % of a GPT-2 large step on MI355X), which is why ``activation_checkpoint="none"``
 keeps everything and is what the benchmark uses on a 288 GB device.
 """

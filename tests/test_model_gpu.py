@@ -153,8 +153,9 @@ def test_full_recompute_reproduces_dropout_masks():
 def test_selective_policy_is_bit_identical_and_keeps_less_memory():
     """"selective" rebuilds both LayerNorm outputs and gelu(u) in backward with the kernels that
     produced them: losses and gradients equal those of the keep-everything run bit for bit, and the
-    peak of allocated memory over forward + backward drops by about 6d of the 22d elements a block
-    keeps per token."""
+    memory held between forward and backward drops by 6d of the 16d elements a block keeps per
+    token (residual stream 2d, QKV 3d, attention output d, u 4d | LayerNorm outputs 2d, gelu(u) 4d);
+    "full" keeps the 2d of each block's input pair."""
     cfg = get_config("gpt2", n_layer=4).without_dropout()
     torch.manual_seed(3)
     base = MyGPT2LMHeadModel(cfg, activation_checkpoint="none").to(device=DEV, dtype=torch.bfloat16)
@@ -182,7 +183,7 @@ def test_selective_policy_is_bit_identical_and_keeps_less_memory():
     saved = peaks["none"] - peaks["selective"]
     expect = cfg.n_layer * tokens * 6 * d * 2
     assert 0.9 * expect <= saved <= 1.1 * expect, (peaks, expect)
-    assert peaks["full"] < 0.5 * peaks["selective"], peaks
+    assert peaks["selective"] - peaks["full"] > cfg.n_layer * tokens * 7.5 * d * 2, peaks
 
 
 def test_graphed_train_step_at_the_gpt2_vocabulary_with_fresh_tokens_every_replay():

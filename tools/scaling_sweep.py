@@ -3,10 +3,19 @@
 
 Every point is one `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` child
 (one process per GPU over RCCL); its JSON line is appended to `<out>/scaling_sweep.jsonl` together
-with the weak-scaling efficiency against the same mode's smallest GPU count, and a table is printed
-at the end. `--tune` additionally sweeps the DDP bucket size and the FSDP unit size (blocks per
-unit) at the largest GPU count and reports the best of each — the two knobs whose optimum depends
-on the xGMI link curve rather than on the model.
+with the weak-scaling efficiency, and a table is printed at the end.
+
+Efficiency as reported here: (tokens/s at N GPUs / N) divided by (tokens/s / N0) of the SAME mode at
+the smallest count N0 in the sweep, per-GPU batch fixed. With N0 = 1 the base point runs the wrapped
+model only under `--wrap-single` (wrapper overhead and forced collectives included in the base, so
+the ratio isolates the fabric); without it the base is the unwrapped single-GPU step (the ratio then
+also contains the wrapper's cost). The end-of-round scaling figure is computed by the build driver
+from its own 1/2/4/8 runs, not by this tool.
+
+`--tune` additionally sweeps, at the largest GPU count, the knobs that the start-up autotuner
+(`parallel/autotune.py`) otherwise sets from its latency / bandwidth fit — DDP bucket size, DDP
+all-reduce vs reduce-scatter + all-gather, FSDP blocks per unit — and reports the best of each, as
+a check of the autotuner's choice against measured step time.
 
   python tools/scaling_sweep.py                              # all visible GPUs, GPT-2 Large
   python tools/scaling_sweep.py --gpus 1 2 --modes ddp fsdp:FULL_SHARD --model gpt2-medium --tune
@@ -89,6 +98,7 @@ def main():
     if args.tune:
         n = counts[-1]
         for flag, mode, strategy, values in (("--bucket-mb", "ddp", "", (16, 32, 64, 128, 256)),
+                                             ("--ddp-decompose", "ddp", "", ("on", "off")),
                                              ("--fsdp-unit-blocks", "fsdp", "FULL_SHARD", (1, 2, 4, 6))):
             best = None
             for v in values:
