@@ -57,8 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None,
                     help="transformer blocks per sharding unit (default: measured at start-up)")
     ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
-    ap.add_argument("--comm", choices=["native", "c10d"], default="native",
-                    help="native = the framework's RCCL communicator; c10d = a torch.distributed group behind the same interface")
+    ap.add_argument("--comm", choices=["auto", "native", "c10d"], default="auto",
+                    help="native = the framework's RCCL communicator; c10d = a torch.distributed group behind the same "
+                         "interface; auto = native after a self-test on every rank, c10d if any rank fails it "
+                         "(the JSON line's comm_backend says which one ran)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--init-device", choices=["auto", "cpu", "gpu"], default="auto",
                     help="construct the model on the host (then move) or directly on the GPU; auto = GPU above 1e9 parameters")
@@ -85,16 +87,27 @@ def _free_port() -> int:
 def launch_ranks(args) -> int:
     """Parent mode: start ``args.gpus`` ranks as a child job and relay its single result line.
     Nothing in this process has initialised a GPU (no HIP call happens before this point)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
+
+    def run(extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
+               *sys.argv[1:], *extra]
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        return proc.returncode, [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
+
+    code, lines = run([])
+    if not lines and args.comm == "auto":
+        # The ranks died before any of them could vote for the fallback (a crash inside the collective
+        # library rather than an error): one more job on the torch.distributed group.
+        print("[bench] no result from the native communicator job (exit %d); retrying with --comm c10d" % code,
+              file=sys.stderr, flush=True)
+        code, lines = run(["--comm", "c10d"])
     if lines:
         print(lines[-1], flush=True)
-    return proc.returncode
+    return code
 
 
 def main():
@@ -156,7 +169,8 @@ def main():
 
     policy = None
     if distributed:
-        comm.init_distributed(backend="rccl" if args.comm == "native" else "c10d", timeout_s=300.0)
+        comm.init_distributed(backend="c10d" if args.comm == "c10d" else "rccl", timeout_s=300.0,
+                              fallback="c10d" if args.comm == "auto" else None)
         if world > 1 and not args.no_comm_autotune:
             policy = autotune.tune(device=device, total_grad_bytes=n_params * (2 if args.dtype == "bf16" else 4),
                                    verbose=True)
@@ -257,8 +271,27 @@ def main():
         return out
 
     kinds = {"single": ["single"], "ddp": ["ddp"], "fsdp": ["fsdp"], "both": ["ddp", "fsdp"]}[mode]
-    results = {k: measure(k) for k in kinds}
-    head = results[kinds[-1]]  # FSDP when both were measured
+    results = {}
+    for k in kinds:
+        if len(kinds) == 1:
+            results[k] = measure(k)
+            continue
+        # Two modes in one job: a failure in one must not lose the other's number. Every rank sees the
+        # same exception class of failure (a collective that times out aborts the communicator on all
+        # of them), and after an abort nothing further can be measured.
+        try:
+            results[k] = measure(k)
+        except Exception as exc:  # noqa: BLE001 - reported in the result line
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            results[k] = {"parallelism": k, "error": repr(exc)[:500]}
+            c = comm.get_communicator()
+            if c is None or getattr(c, "aborted", False):
+                break
+    good = [k for k in kinds if k in results and "error" not in results[k]]
+    if not good:
+        raise SystemExit(f"no mode could be measured: {results}")
+    head = results[good[-1]]  # FSDP when both were measured
 
     if rank == 0:
         global_batch = args.batch_per_gpu * world

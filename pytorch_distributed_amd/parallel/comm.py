@@ -49,11 +49,82 @@ def _store_port() -> int:
     return int(os.environ.get("MASTER_PORT", "29500")) + 1
 
 
-def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) -> Tuple[int, int, torch.device]:
+def _self_test(comm, device: torch.device) -> None:
+    """Every collective once on its queue, with values whose result is known, then a device sync."""
+    r, w = comm.rank, comm.world_size
+    if os.environ.get("PDA_COMM_SELFTEST_FAIL_RANK") == str(r):  # fault injection for the fallback test
+        raise RuntimeError("communicator self-test: injected failure")
+    n = 1 << 16
+    a = torch.full((n,), float(r + 1), device=device)
+    comm.all_reduce(a, "sum", 1).wait()
+    mine = torch.full((n,), float(r), device=device, dtype=torch.bfloat16)
+    gathered = torch.empty(w * n, device=device, dtype=torch.bfloat16)
+    comm.all_gather(gathered, mine, 0).wait()
+    wide = torch.arange(w, device=device, dtype=torch.float32).repeat_interleave(n) + r
+    part = torch.empty(n, device=device)
+    comm.reduce_scatter(part, wide, "avg", 1).wait()
+    b = torch.full((n,), float(r), device=device)
+    comm.broadcast(b, w - 1, 0).wait()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    ok = (bool((a == w * (w + 1) / 2).all())
+          and bool((gathered.view(w, n).float() == torch.arange(w, device=device).view(w, 1)).all())
+          and bool(torch.allclose(part, torch.full_like(part, r + (w - 1) / 2)))
+          and bool((b == w - 1).all()))
+    if not ok:
+        raise RuntimeError("communicator self-test: a collective returned wrong values")
+
+
+def _verified_native(create, device, probe_timeout_s: float):
+    """Builds the native communicator in a helper thread, self-tests it, and lets the ranks vote
+    (through the rendezvous store, which does not depend on the collective library). Returns the
+    communicator, or None when any rank failed or timed out."""
+    import threading
+
+    box = {}
+
+    def work():
+        try:
+            box["comm"] = create()
+            _self_test(box["comm"], device)
+            box["ok"] = True
+        except BaseException as exc:  # noqa: BLE001 - reported below, the caller falls back
+            box["error"] = repr(exc)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(probe_timeout_s)
+    mine_ok = bool(box.get("ok"))
+    if not mine_ok:
+        print(f"[comm] native communicator unusable on rank {env_rank_world()[0]}: "
+              f"{box.get('error', f'no answer within {probe_timeout_s:.0f} s')}", flush=True)
+    comm = box.get("comm")
+    all_ok = False
+    if comm is not None:
+        try:
+            all_ok = all(v == b"1" for v in comm.exchange(b"1" if mine_ok else b"0"))
+        except Exception as exc:  # noqa: BLE001 - a peer never built its communicator
+            print(f"[comm] vote failed on rank {env_rank_world()[0]}: {exc!r}", flush=True)
+    if all_ok:
+        return comm
+    if comm is not None:
+        try:
+            comm.abort()
+        except Exception:  # noqa: BLE001
+            pass
+    return None
+
+
+def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fallback: Optional[str] = None,
+                     probe_timeout_s: float = 150.0) -> Tuple[int, int, torch.device]:
     """Creates the process-wide communicator from the torchrun environment.
 
     ``backend``: ``"rccl"`` (alias ``"nccl"``), ``"socket"`` (alias ``"gloo"``: the CPU backend),
     ``"c10d"`` or None = RCCL when a GPU is visible, the socket mesh otherwise.
+    ``fallback="c10d"`` (multi-rank RCCL only): the native communicator is built and self-tested
+    under ``probe_timeout_s``, the ranks vote, and unless every rank passed, all of them switch to a
+    ``torch.distributed`` group behind the same interface — a job then still runs (and says so:
+    ``get_communicator().backend`` starts with ``c10d:``) on a machine where the native path fails.
     Returns ``(rank, world_size, device)``. Safe to call when already initialised.
     """
     global _COMM, _DEVICE, _OWNS_C10D
@@ -63,6 +134,8 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) ->
     backend = {"nccl": "rccl", "gloo": "socket", None: None}.get(backend, backend)
     if backend is None:
         backend = os.environ.get("PDA_COMM_BACKEND") or ("rccl" if torch.cuda.is_available() else "socket")
+    if fallback not in (None, "c10d"):
+        raise ValueError("fallback must be None or 'c10d'")
     ext = _ext.require()
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
     job = os.environ.get("PDA_JOB_ID") or f"{host}:{os.environ.get('MASTER_PORT', '29500')}"
@@ -72,10 +145,25 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0) ->
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(device)
         torch.zeros(1, device=device)  # the HIP context exists before RCCL initialises
-        _COMM = ext.create_communicator("rccl", rank, world, host, _store_port(), local_rank, timeout_s, job)
+        create = lambda: ext.create_communicator("rccl", rank, world, host, _store_port(), local_rank,  # noqa: E731
+                                                 timeout_s, job)
+        if fallback == "c10d" and world > 1:
+            _COMM = _verified_native(create, device, probe_timeout_s)
+            if _COMM is None:
+                backend = "c10d"
+        else:
+            _COMM = create()
     elif backend == "socket":
         device = torch.device("cpu")
-        _COMM = ext.create_communicator("socket", rank, world, host, _store_port(), 0, timeout_s, job)
+        create = lambda: ext.create_communicator("socket", rank, world, host, _store_port(), 0, timeout_s, job)  # noqa: E731
+        if fallback == "c10d" and world > 1:
+            _COMM = _verified_native(create, device, probe_timeout_s)
+            if _COMM is None:
+                backend = "c10d"
+        else:
+            _COMM = create()
+    if _COMM is not None:
+        pass
     elif backend == "c10d":
         import torch.distributed as dist
 

@@ -7,6 +7,7 @@ import copy
 import pytest
 import torch
 
+from tests import dist_utils
 from tests.dist_utils import run_distributed
 from tests.test_ddp_cpu import _batch, _tiny_model
 
@@ -280,3 +281,53 @@ def test_accumulator_post_hook_fires_when_an_op_returns_no_gradient():
         Fn.apply(x, w).sum().backward()
         assert len(fired) == k + 1, "AccumulateGrad post-hook did not fire for a None gradient"
     assert w.grad is None and sink.abs().sum() > 0
+
+
+def _fallback_worker(rank, world, expect_prefix):
+    from pytorch_distributed_amd import parallel
+
+    comm = parallel.get_communicator()
+    assert comm.backend.startswith(expect_prefix), comm.backend
+    t = torch.full((1000,), float(rank + 1))
+    parallel.all_reduce(t)
+    assert bool((t == world * (world + 1) / 2).all())
+
+
+def _entry_with_fallback(rank, world, port, fail_rank, expect_prefix, err_dir):
+    import os
+    import sys
+    import traceback
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    if fail_rank is not None:
+        os.environ["PDA_COMM_SELFTEST_FAIL_RANK"] = str(fail_rank)
+    sys.path.insert(0, dist_utils.ROOT)
+    try:
+        from pytorch_distributed_amd.parallel import init_distributed, shutdown
+
+        init_distributed(backend="socket", timeout_s=60, fallback="c10d", probe_timeout_s=30)
+        _fallback_worker(rank, world, expect_prefix)
+        shutdown()
+    except BaseException:  # noqa: BLE001
+        with open(os.path.join(err_dir, f"rank{rank}.err"), "w") as f:
+            f.write(traceback.format_exc()[-4000:])
+        os._exit(1)
+
+
+@pytest.mark.parametrize("fail_rank,expect", [(None, "socket"), (1, "c10d:gloo")])
+def test_verified_init_keeps_native_or_falls_back_on_every_rank(fail_rank, expect, tmp_path):
+    """init_distributed(fallback="c10d"): all ranks pass the self-test -> native communicator; one
+    rank fails it -> every rank switches to the torch.distributed group behind the same interface."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    port = dist_utils.free_port()
+    procs = [ctx.Process(target=_entry_with_fallback, args=(r, 3, port, fail_rank, expect, str(tmp_path)))
+             for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    errs = [f.read_text() for f in tmp_path.glob("rank*.err")]
+    assert not errs and all(p.exitcode == 0 for p in procs), "\n".join(errs)
