@@ -85,6 +85,8 @@ def _verified_native(create, device, probe_timeout_s: float):
 
     def work():
         try:
+            if device.type == "cuda":
+                torch.cuda.set_device(device)  # the current device is a per-thread setting
             box["comm"] = create()
             _self_test(box["comm"], device)
             box["ok"] = True
@@ -121,7 +123,7 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
 
     ``backend``: ``"rccl"`` (alias ``"nccl"``), ``"socket"`` (alias ``"gloo"``: the CPU backend),
     ``"c10d"`` or None = RCCL when a GPU is visible, the socket mesh otherwise.
-    ``fallback="c10d"`` (multi-rank RCCL only): the native communicator is built and self-tested
+    ``fallback="c10d"``: the native communicator is built and self-tested
     under ``probe_timeout_s``, the ranks vote, and unless every rank passed, all of them switch to a
     ``torch.distributed`` group behind the same interface — a job then still runs (and says so:
     ``get_communicator().backend`` starts with ``c10d:``) on a machine where the native path fails.
@@ -147,7 +149,7 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
         torch.zeros(1, device=device)  # the HIP context exists before RCCL initialises
         create = lambda: ext.create_communicator("rccl", rank, world, host, _store_port(), local_rank,  # noqa: E731
                                                  timeout_s, job)
-        if fallback == "c10d" and world > 1:
+        if fallback == "c10d":
             _COMM = _verified_native(create, device, probe_timeout_s)
             if _COMM is None:
                 backend = "c10d"
@@ -156,7 +158,7 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
     elif backend == "socket":
         device = torch.device("cpu")
         create = lambda: ext.create_communicator("socket", rank, world, host, _store_port(), 0, timeout_s, job)  # noqa: E731
-        if fallback == "c10d" and world > 1:
+        if fallback == "c10d":
             _COMM = _verified_native(create, device, probe_timeout_s)
             if _COMM is None:
                 backend = "c10d"
