@@ -324,7 +324,7 @@ def main():
         from pytorch_distributed_amd import _ext
         st = _ext.require().gemm_planner_stats()
         for row in sorted(st["table"]):
-            print("planner m=%d n=%d k=%d ta=%d tb=%d ep=%d candidates=%d chosen=%d first=%.1fus best=%.1fus"
+            print("planner m=%d n=%d k=%d ta=%d tb=%d ep=%d candidates=%d chosen=%d first=%.1fus best=%.1fus solution=%d"
                   % tuple(row), file=sys.stderr)
     if distributed:
         comm.barrier()

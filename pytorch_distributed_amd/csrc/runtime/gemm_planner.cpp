@@ -15,12 +15,18 @@
 // in place on the caller's stream with the caller's operands (every epilogue used here is
 // idempotent, so re-running a candidate is harmless). Plans live for the life of the process.
 //
+// Candidates: the heuristic's best `max_candidates`, and in exhaustive mode every kernel of the
+// library that supports the problem (hipblaslt_ext::getAllAlgos + matmulIsAlgoSupported; the
+// heuristic's list is drawn from tables tuned for other sizes and regularly misses the best kernel
+// for a given shape by 5-20 %). An exhaustive search costs seconds per shape, so its results are
+// meant to be kept: a choice is identified by the library's solution index, which is stable for a
+// given library build, exported with export_choices() and stored by tuning/gemm_plans.py in a file
+// that later processes import before their first GEMM (no timing at all for known shapes).
+//
 // Data-parallel jobs: every rank would otherwise time on its own and ranks could settle on
 // different kernels for the same problem (a few percent apart, i.e. a permanent straggler).
-// export_choices() / import_choices() move one rank's table to the others: the heuristic's
-// candidate list is deterministic for a given library and device, so the index of the winner
-// is portable. parallel/plan_sync.py runs a planning pass before the model is wrapped and
-// installs rank 0's choices everywhere.
+// The same export / import moves one rank's table to the others: parallel/plan_sync.py runs a
+// planning pass before the model is wrapped and installs rank 0's choices everywhere.
 //
 // All matrices are ROW-major with unit column stride and an arbitrary row stride; hipBLASLt
 // is column-major, so out[M,N] = A'[M,K] . B'[K,N] is issued as out^T = B'^T . A'^T.
@@ -29,6 +35,7 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 #include <torch/extension.h>
 
 #include <algorithm>
@@ -78,8 +85,9 @@ struct Plan {
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lo = nullptr;
   hipblasLtMatmulAlgo_t algo;
   size_t workspace = 0;
-  int candidates = 0;
-  int chosen = 0;
+  int candidates = 0;   // -1: algorithm not chosen yet
+  int chosen = 0;       // position of the winner in the candidate list (statistics only)
+  int solution = -1;    // the library's solution index of the winner (portable between processes)
   float best_us = 0.f, first_us = 0.f;
 };
 
@@ -95,6 +103,7 @@ class Planner {
   }
 
   bool tuning = true;
+  bool exhaustive = false;
   int max_candidates = 48;
   int timed_runs = 4;
   size_t workspace_limit = size_t(64) << 20;
@@ -125,19 +134,19 @@ class Planner {
 
   using Choice = std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, bool, bool, int, int>;
 
-  // (m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue, chosen candidate) of every tuned plan.
+  // (m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue, solution index) of every chosen plan.
   std::vector<Choice> export_choices() {
     std::lock_guard<std::mutex> lock(mu_);
     std::vector<Choice> out;
     for (auto& kv : plans_) {
       const Key& k = kv.first;
-      if (kv.second.candidates > 0)
-        out.emplace_back(k.m, k.n, k.k, k.lda, k.ldb, k.ldo, k.trans_a, k.trans_b, k.epilogue, kv.second.chosen);
+      if (kv.second.candidates > 0 && kv.second.solution >= 0)
+        out.emplace_back(k.m, k.n, k.k, k.lda, k.ldb, k.ldo, k.trans_a, k.trans_b, k.epilogue, kv.second.solution);
     }
     return out;
   }
 
-  // Pins the candidate index per problem; plans already made for those problems are re-chosen
+  // Pins the solution per problem; plans already made for those problems are re-chosen
   // (without timing) the next time they run.
   void import_choices(const std::vector<Choice>& rows) {
     std::lock_guard<std::mutex> lock(mu_);
@@ -148,9 +157,22 @@ class Planner {
       for (auto& kv : plans_) {
         Key probe = kv.first;
         probe.device = 0;
-        if (!(probe < k) && !(k < probe) && kv.second.chosen != std::get<9>(r)) kv.second.candidates = -1;
+        if (!(probe < k) && !(k < probe) && kv.second.solution != std::get<9>(r)) kv.second.candidates = -1;
       }
     }
+  }
+
+  // Identifies the library build the solution indices belong to.
+  std::string library_tag() {
+    std::lock_guard<std::mutex> lock(mu_);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    int version = 0;
+    PDA_LT_CHECK(hipblasLtGetVersion(handle_for(device), &version));
+    hipDeviceProp_t prop;
+    PDA_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    std::string arch = prop.gcnArchName;
+    return "hipblaslt-" + std::to_string(version) + "/" + arch.substr(0, arch.find(':'));
   }
 
   py::dict stats() {
@@ -164,7 +186,7 @@ class Planner {
       const Key& k = kv.first;
       const Plan& p = kv.second;
       rows.append(py::make_tuple(k.m, k.n, k.k, k.trans_a, k.trans_b, k.epilogue, p.candidates, p.chosen,
-                                 p.first_us, p.best_us));
+                                 p.first_us, p.best_us, p.solution));
     }
     d["table"] = rows;
     return d;
@@ -245,6 +267,26 @@ class Planner {
 
   void choose(hipblasLtHandle_t handle, Plan& p, const at::Tensor& a, const at::Tensor& b, at::Tensor& out, void* ws,
               hipStream_t stream, int pinned) {
+    const float alpha = 1.f, beta = 0.f;
+    auto supported = [&](hipblasLtMatmulAlgo_t& algo) {
+      size_t need = 0;
+      return hipblaslt_ext::matmulIsAlgoSupported(handle, p.desc, &alpha, p.la, p.lb, &beta, p.lo, p.lo, algo, need) ==
+                 HIPBLAS_STATUS_SUCCESS &&
+             need <= workspace_limit;
+    };
+    // A solution adopted from a plan file or from another rank: no timing.
+    if (pinned >= 0) {
+      std::vector<int> index{pinned};
+      std::vector<hipblasLtMatmulHeuristicResult_t> got;
+      if (hipblaslt_ext::getAlgosFromIndex(handle, index, got) == HIPBLAS_STATUS_SUCCESS && !got.empty() &&
+          supported(got[0].algo)) {
+        p.algo = got[0].algo;
+        p.candidates = 1;
+        p.chosen = 0;
+        p.solution = pinned;
+        return;
+      }
+    }
     hipblasLtMatmulPreference_t pref;
     PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
     PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
@@ -260,39 +302,62 @@ class Planner {
     p.candidates = returned;
     p.chosen = 0;
     p.algo = found[0].algo;
-    if (pinned >= 0 && pinned < returned && found[pinned].state == HIPBLAS_STATUS_SUCCESS) {
-      p.chosen = pinned;  // another rank's measured winner: adopt it, do not time
-      p.algo = found[pinned].algo;
-      return;
-    }
+    p.solution = hipblaslt_ext::getIndexFromAlgo(found[0].algo);
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &capturing);
-    if (!tuning || returned == 1 || capturing != hipStreamCaptureStatusNone) return;
+    if (!tuning || capturing != hipStreamCaptureStatusNone) return;
+
+    if (exhaustive) {
+      // Every kernel of the library for this operand layout / type that accepts the problem.
+      hipblasOperation_t op_first, op_second;
+      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first), nullptr));
+      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second), nullptr));
+      std::vector<hipblasLtMatmulHeuristicResult_t> all;
+      if (hipblaslt_ext::getAllAlgos(handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, op_first, op_second, HIP_R_16BF,
+                                     HIP_R_16BF, HIP_R_16BF, HIP_R_16BF, HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS) {
+        std::vector<int> have;
+        for (auto& f : found) have.push_back(hipblaslt_ext::getIndexFromAlgo(f.algo));
+        for (auto& cand : all) {
+          const int idx = hipblaslt_ext::getIndexFromAlgo(cand.algo);
+          if (std::find(have.begin(), have.end(), idx) != have.end()) continue;
+          if (!supported(cand.algo)) continue;
+          cand.state = HIPBLAS_STATUS_SUCCESS;
+          cand.workspaceSize = 0;  // checked against the limit by supported()
+          found.push_back(cand);
+          have.push_back(idx);
+        }
+      }
+      p.candidates = (int)found.size();
+    }
+    if (found.size() == 1) return;
 
     hipEvent_t e0, e1;
     PDA_HIP_CHECK(hipEventCreate(&e0));
     PDA_HIP_CHECK(hipEventCreate(&e1));
-    auto time_us = [&](int i) {
+    auto time_us = [&](int i, int runs) {
       PDA_HIP_CHECK(hipEventRecord(e0, stream));
-      for (int r = 0; r < timed_runs; ++r) launch(handle, p, found[i].algo, a, b, out, ws, stream);
+      for (int r = 0; r < runs; ++r) launch(handle, p, found[i].algo, a, b, out, ws, stream);
       PDA_HIP_CHECK(hipEventRecord(e1, stream));
       PDA_HIP_CHECK(hipEventSynchronize(e1));
       float ms = 0.f;
       PDA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-      return ms * 1e3f / timed_runs;
+      return ms * 1e3f / runs;
     };
-    // Pass 1: every valid candidate once.
+    // Pass 1: every valid candidate; one run first, and the full measurement only for those within
+    // reach of the leader (an exhaustive list is mostly kernels several times too slow).
     std::vector<std::pair<float, int>> timed;
-    for (int i = 0; i < returned; ++i) {
+    float leader = 1e30f;
+    for (int i = 0; i < (int)found.size(); ++i) {
       if (found[i].state != HIPBLAS_STATUS_SUCCESS || found[i].workspaceSize > workspace_limit) continue;
-      const float alpha = 1.f, beta = 0.f;
       // warm-up run doubles as the validity check of the candidate
       hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, b.data_ptr(), p.la, a.data_ptr(), p.lb, &beta,
                                            out.data_ptr(), p.lo, out.data_ptr(), p.lo, &found[i].algo, ws,
                                            workspace_limit, stream);
       if (st != HIPBLAS_STATUS_SUCCESS) continue;
-      const float us = time_us(i);
+      float us = time_us(i, 1);
+      if (i == 0 || us <= 1.25f * leader) us = time_us(i, timed_runs);
       if (i == 0) p.first_us = us;
+      leader = std::min(leader, us);
       timed.emplace_back(us, i);
     }
     float best = 1e30f;
@@ -302,11 +367,12 @@ class Planner {
       // in alternation and the lowest total wins.
       std::sort(timed.begin(), timed.end());
       std::vector<std::pair<float, int>> finalists;
+      const size_t keep = exhaustive ? 8 : 4;
       for (const auto& t : timed)
-        if (finalists.size() < 4 && t.first <= timed[0].first * 1.05f) finalists.emplace_back(0.f, t.second);
+        if (finalists.size() < keep && t.first <= timed[0].first * 1.05f) finalists.emplace_back(0.f, t.second);
       if (finalists.size() > 1) {
         for (int round = 0; round < 3; ++round)
-          for (auto& f : finalists) f.first += time_us(f.second);
+          for (auto& f : finalists) f.first += time_us(f.second, timed_runs);
         std::sort(finalists.begin(), finalists.end());
         best = finalists[0].first / 3.f;
       } else {
@@ -314,6 +380,7 @@ class Planner {
       }
       p.chosen = finalists[0].second;
       p.algo = found[p.chosen].algo;
+      p.solution = hipblaslt_ext::getIndexFromAlgo(p.algo);
     }
     p.best_us = best;
     (void)hipEventDestroy(e0);
@@ -369,15 +436,19 @@ void bind_gemm(py::module_& m) {
         py::arg("out") = py::none(), py::arg("epilogue") = "none", py::arg("bias") = py::none(),
         "Row-major bf16 GEMM with an optional fused bias add (epilogue 'none' | 'bias'); the algorithm is "
         "picked by timing the library's candidates on first use of each problem.");
-  m.def("gemm_planner_configure", [](bool tuning, int max_candidates, int timed_runs) {
+  m.def("gemm_planner_configure", [](bool tuning, int max_candidates, int timed_runs, bool exhaustive) {
     auto& p = Planner::get();
     p.tuning = tuning;
     p.max_candidates = max_candidates;
     p.timed_runs = timed_runs;
-  }, py::arg("tuning") = true, py::arg("max_candidates") = 48, py::arg("timed_runs") = 4);
+    p.exhaustive = exhaustive;
+  }, py::arg("tuning") = true, py::arg("max_candidates") = 48, py::arg("timed_runs") = 4,
+     py::arg("exhaustive") = false);
+  m.def("gemm_planner_library", []() { return Planner::get().library_tag(); },
+        "identifies the library build + architecture that exported solution indices belong to");
   m.def("gemm_planner_stats", []() { return Planner::get().stats(); });
   m.def("gemm_planner_export", []() { return Planner::get().export_choices(); },
-        "(m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue, chosen) of every tuned plan");
+        "(m, n, k, lda, ldb, ldo, trans_a, trans_b, epilogue, solution index) of every chosen plan");
   m.def("gemm_planner_import", [](const std::vector<Planner::Choice>& rows) { Planner::get().import_choices(rows); },
         py::arg("rows"), "adopt another rank's choices (see gemm_planner_export)");
 }

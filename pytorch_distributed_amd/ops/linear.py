@@ -45,7 +45,11 @@ def _native_wgrad_ok(dy2: torch.Tensor, x2: torch.Tensor) -> bool:
     return _ext.require().wgrad_supported(dy2.shape[0], dy2.shape[1], x2.shape[1])
 
 
+_PLAN_FILE_CHECKED = False
+
+
 def _planner_ok(*mats: torch.Tensor) -> bool:
+    global _PLAN_FILE_CHECKED
     if os.environ.get("PDA_NO_GEMM_PLANNER") == "1":
         return False
     for m in mats:
@@ -53,6 +57,10 @@ def _planner_ok(*mats: torch.Tensor) -> bool:
                 and m.stride(0) % 8 == 0 and m.stride(0) >= m.shape[1] and m.data_ptr() % 16 == 0
                 and m.numel() > 0):
             return False
+    if not _PLAN_FILE_CHECKED:  # searched-once kernel choices, adopted before the first planned GEMM
+        _PLAN_FILE_CHECKED = True
+        from ..tuning import gemm_plans
+        gemm_plans.load_default_once()
     return True
 
 
