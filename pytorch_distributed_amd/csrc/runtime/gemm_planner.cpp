@@ -307,6 +307,50 @@ class Planner {
     (void)hipStreamIsCapturing(stream, &capturing);
     if (!tuning || capturing != hipStreamCaptureStatusNone) return;
 
+    static const bool siblings = std::getenv("PDA_NO_SIBLING_CANDIDATES") == nullptr;  // A/B switch
+    if (siblings) {
+      // The heuristic's list depends on the epilogue: asked for the same shape with the other
+      // epilogue it proposes other kernels, and most kernels serve both. Measured on MI355X for
+      // m=32768 n=5120 k=1280: best of the plain list 367 us, best of the bias list 297 us. So the
+      // sibling list is added to the candidates (those that accept this problem).
+      hipblasLtMatmulDesc_t sibling;
+      PDA_LT_CHECK(hipblasLtMatmulDescCreate(&sibling, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+      hipblasOperation_t op_first, op_second;
+      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first), nullptr));
+      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second), nullptr));
+      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first)));
+      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second)));
+      hipblasLtEpilogue_t mine = HIPBLASLT_EPILOGUE_DEFAULT;
+      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &mine, sizeof(mine), nullptr));
+      const hipblasLtEpilogue_t other = mine == HIPBLASLT_EPILOGUE_BIAS ? HIPBLASLT_EPILOGUE_DEFAULT : HIPBLASLT_EPILOGUE_BIAS;
+      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_EPILOGUE, &other, sizeof(other)));
+      if (other == HIPBLASLT_EPILOGUE_BIAS) {
+        const int32_t bias_type = HIP_R_16BF;
+        PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)));
+      }
+      hipblasLtMatmulPreference_t pref2;
+      PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref2));
+      PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref2, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
+                                                         &workspace_limit, sizeof(workspace_limit)));
+      std::vector<hipblasLtMatmulHeuristicResult_t> more(want);
+      int got = 0;
+      if (hipblasLtMatmulAlgoGetHeuristic(handle, sibling, p.la, p.lb, p.lo, p.lo, pref2, want, more.data(), &got) ==
+          HIPBLAS_STATUS_SUCCESS) {
+        std::vector<int> have;
+        for (auto& f : found) have.push_back(hipblaslt_ext::getIndexFromAlgo(f.algo));
+        for (int i = 0; i < got; ++i) {
+          const int idx = hipblaslt_ext::getIndexFromAlgo(more[i].algo);
+          if (more[i].state != HIPBLAS_STATUS_SUCCESS || std::find(have.begin(), have.end(), idx) != have.end()) continue;
+          if (!supported(more[i].algo)) continue;
+          more[i].workspaceSize = 0;
+          found.push_back(more[i]);
+          have.push_back(idx);
+        }
+      }
+      hipblasLtMatmulPreferenceDestroy(pref2);
+      hipblasLtMatmulDescDestroy(sibling);
+      p.candidates = (int)found.size();
+    }
     if (exhaustive) {
       // Every kernel of the library for this operand layout / type that accepts the problem.
       hipblasOperation_t op_first, op_second;

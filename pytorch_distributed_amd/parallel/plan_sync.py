@@ -32,7 +32,7 @@ _linear = importlib.import_module("pytorch_distributed_amd.ops.linear")  # the m
 def export_decisions() -> dict:
     ext = _ext.require()
     return {"planner": [list(r) for r in ext.gemm_planner_export()],
-            "dgrad": [[list(k[1:]), bool(v)] for k, v in _linear._DGRAD_TRANSPOSED.items()]}
+            "dgrad": [[list(k[1:]), int(v)] for k, v in _linear._DGRAD_TRANSPOSED.items()]}
 
 
 def import_decisions(decisions: dict, device_index: Optional[int] = None) -> None:
@@ -42,7 +42,7 @@ def import_decisions(decisions: dict, device_index: Optional[int] = None) -> Non
     if device_index is None:
         device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
     for key, choice in decisions["dgrad"]:
-        _linear._DGRAD_TRANSPOSED[(device_index, *[int(x) for x in key])] = bool(choice)
+        _linear._DGRAD_TRANSPOSED[(device_index, *[int(x) for x in key])] = int(choice)
 
 
 def sync_decisions(communicator=None) -> int:

@@ -45,7 +45,7 @@ def current_table() -> dict:
     lin = _linear()
     return {"library": ext.gemm_planner_library(),
             "planner": sorted(list(int(x) for x in r) for r in ext.gemm_planner_export()),
-            "dgrad": sorted([list(k[1:]), bool(v)] for k, v in lin._DGRAD_TRANSPOSED.items())}
+            "dgrad": sorted([list(k[1:]), int(v)] for k, v in lin._DGRAD_TRANSPOSED.items())}
 
 
 def save(path: str = PLAN_FILE, merge: bool = True) -> dict:
@@ -85,7 +85,7 @@ def load(path: str = PLAN_FILE, device_index: Optional[int] = None) -> int:
         if device_index is None:
             device_index = torch.cuda.current_device()
         for key, choice in table.get("dgrad", []):
-            lin._DGRAD_TRANSPOSED.setdefault((device_index, *[int(x) for x in key]), bool(choice))
+            lin._DGRAD_TRANSPOSED.setdefault((device_index, *[int(x) for x in key]), int(choice))
         return len(rows)
     except Exception:  # noqa: BLE001 - a bad plan file must never stop training
         return 0
