@@ -4,8 +4,9 @@
 // The forward and data-gradient GEMMs of a transformer are plain library GEMMs (the
 // weight-gradient shape has its own kernel, kernels/gemm_wgrad.hip). Two things are left on
 // the table when they are issued through a generic matmul call:
-//   * the library's default heuristic is regularly 5-15 % off its own best kernel on gfx950
-//     for the tall shapes of training (M = tokens = 16-64 K);
+//   * the library's default heuristic is for some of the tall shapes of training (M = tokens =
+//     16-64 K) several percent off its own best kernel on gfx950, and which shapes those are
+//     changes with the layout and the epilogue;
 //   * a bias add run as its own kernel costs a full HBM round trip of the output; the library
 //     applies it in the GEMM epilogue. (Its GELU epilogues are not used: on this library build
 //     GELU_AUX has no bf16 kernel at all and DGELU runs 4x slower than GEMM + a separate
@@ -258,8 +259,15 @@ class Planner {
       PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
   }
 
-  void launch(hipblasLtHandle_t handle, const Plan& p, const hipblasLtMatmulAlgo_t& algo, const at::Tensor& a,
-              const at::Tensor& b, at::Tensor& out, void* ws, hipStream_t stream) {
+  hipblasStatus_t try_launch(hipblasLtHandle_t handle, const Plan& p, const hipblasLtMatmulAlgo_t& algo,
+                             const at::Tensor& a, const at::Tensor& b, at::Tensor& out, void* ws, hipStream_t stream) {
+    const float alpha = 1.f, beta = 0.f;
+    return hipblasLtMatmul(handle, p.desc, &alpha, b.data_ptr(), p.la, a.data_ptr(), p.lb, &beta,
+                           out.data_ptr(), p.lo, out.data_ptr(), p.lo, &algo, ws, workspace_limit, stream);
+  }
+
+  void launch(hipblasLtHandle_t handle, const Plan& p, const hipblasLtMatmulAlgo_t& algo,
+              const at::Tensor& a, const at::Tensor& b, at::Tensor& out, void* ws, hipStream_t stream) {
     const float alpha = 1.f, beta = 0.f;
     PDA_LT_CHECK(hipblasLtMatmul(handle, p.desc, &alpha, b.data_ptr(), p.la, a.data_ptr(), p.lb, &beta,
                                  out.data_ptr(), p.lo, out.data_ptr(), p.lo, &algo, ws, workspace_limit, stream));
@@ -274,130 +282,88 @@ class Planner {
                  HIPBLAS_STATUS_SUCCESS &&
              need <= workspace_limit;
     };
+    auto adopt = [&](hipblasLtMatmulAlgo_t& algo, int position, int total) {
+      p.algo = algo;
+      p.chosen = position;
+      p.candidates = total;
+      p.solution = hipblaslt_ext::getIndexFromAlgo(p.algo);
+    };
     // A solution adopted from a plan file or from another rank: no timing.
     if (pinned >= 0) {
       std::vector<int> index{pinned};
       std::vector<hipblasLtMatmulHeuristicResult_t> got;
       if (hipblaslt_ext::getAlgosFromIndex(handle, index, got) == HIPBLAS_STATUS_SUCCESS && !got.empty() &&
           supported(got[0].algo)) {
-        p.algo = got[0].algo;
-        p.candidates = 1;
-        p.chosen = 0;
-        p.solution = pinned;
+        adopt(got[0].algo, 0, 1);
         return;
       }
     }
-    hipblasLtMatmulPreference_t pref;
-    PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
-    PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
-                                                       &workspace_limit, sizeof(workspace_limit)));
     const int want = tuning ? std::max(1, max_candidates) : 1;
-    std::vector<hipblasLtMatmulHeuristicResult_t> found(want);
-    int returned = 0;
-    PDA_LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lo, p.lo, pref, want, found.data(),
-                                                 &returned));
-    hipblasLtMatmulPreferenceDestroy(pref);
-    TORCH_CHECK(returned > 0, "hipBLASLt has no algorithm for this GEMM (m=", out.size(0), " n=", out.size(1), ")");
-    found.resize(returned);
-    p.candidates = returned;
-    p.chosen = 0;
-    p.algo = found[0].algo;
-    p.solution = hipblaslt_ext::getIndexFromAlgo(found[0].algo);
+    std::vector<hipblasLtMatmulAlgo_t> cands;
+    std::vector<int> have;
+    auto add = [&](hipblasLtMatmulAlgo_t& algo) {
+      const int idx = hipblaslt_ext::getIndexFromAlgo(algo);
+      if (std::find(have.begin(), have.end(), idx) != have.end()) return;
+      have.push_back(idx);
+      cands.push_back(algo);
+    };
+    {
+      hipblasLtMatmulPreference_t pref;
+      PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+      PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
+                                                         &workspace_limit, sizeof(workspace_limit)));
+      std::vector<hipblasLtMatmulHeuristicResult_t> found(want);
+      int returned = 0;
+      PDA_LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.la, p.lb, p.lo, p.lo, pref, want, found.data(),
+                                                   &returned));
+      hipblasLtMatmulPreferenceDestroy(pref);
+      for (int i = 0; i < returned; ++i)
+        if (found[i].state == HIPBLAS_STATUS_SUCCESS && found[i].workspaceSize <= workspace_limit) add(found[i].algo);
+    }
+    TORCH_CHECK(!cands.empty(), "hipBLASLt has no algorithm for this GEMM (m=", out.size(0), " n=", out.size(1), ")");
+    adopt(cands[0], 0, (int)cands.size());
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &capturing);
     if (!tuning || capturing != hipStreamCaptureStatusNone) return;
 
-    static const bool siblings = std::getenv("PDA_NO_SIBLING_CANDIDATES") == nullptr;  // A/B switch
-    if (siblings) {
-      // The heuristic's list depends on the epilogue: asked for the same shape with the other
-      // epilogue it proposes other kernels, and most kernels serve both. Measured on MI355X for
-      // m=32768 n=5120 k=1280: best of the plain list 367 us, best of the bias list 297 us. So the
-      // sibling list is added to the candidates (those that accept this problem).
-      hipblasLtMatmulDesc_t sibling;
-      PDA_LT_CHECK(hipblasLtMatmulDescCreate(&sibling, HIPBLAS_COMPUTE_32F, HIP_R_32F));
-      hipblasOperation_t op_first, op_second;
-      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first), nullptr));
-      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second), nullptr));
-      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first)));
-      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second)));
-      hipblasLtEpilogue_t mine = HIPBLASLT_EPILOGUE_DEFAULT;
-      PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &mine, sizeof(mine), nullptr));
-      const hipblasLtEpilogue_t other = mine == HIPBLASLT_EPILOGUE_BIAS ? HIPBLASLT_EPILOGUE_DEFAULT : HIPBLASLT_EPILOGUE_BIAS;
-      PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_EPILOGUE, &other, sizeof(other)));
-      if (other == HIPBLASLT_EPILOGUE_BIAS) {
-        const int32_t bias_type = HIP_R_16BF;
-        PDA_LT_CHECK(hipblasLtMatmulDescSetAttribute(sibling, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)));
-      }
-      hipblasLtMatmulPreference_t pref2;
-      PDA_LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref2));
-      PDA_LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref2, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES,
-                                                         &workspace_limit, sizeof(workspace_limit)));
-      std::vector<hipblasLtMatmulHeuristicResult_t> more(want);
-      int got = 0;
-      if (hipblasLtMatmulAlgoGetHeuristic(handle, sibling, p.la, p.lb, p.lo, p.lo, pref2, want, more.data(), &got) ==
-          HIPBLAS_STATUS_SUCCESS) {
-        std::vector<int> have;
-        for (auto& f : found) have.push_back(hipblaslt_ext::getIndexFromAlgo(f.algo));
-        for (int i = 0; i < got; ++i) {
-          const int idx = hipblaslt_ext::getIndexFromAlgo(more[i].algo);
-          if (more[i].state != HIPBLAS_STATUS_SUCCESS || std::find(have.begin(), have.end(), idx) != have.end()) continue;
-          if (!supported(more[i].algo)) continue;
-          more[i].workspaceSize = 0;
-          found.push_back(more[i]);
-          have.push_back(idx);
-        }
-      }
-      hipblasLtMatmulPreferenceDestroy(pref2);
-      hipblasLtMatmulDescDestroy(sibling);
-      p.candidates = (int)found.size();
-    }
     if (exhaustive) {
       // Every kernel of the library for this operand layout / type that accepts the problem.
+      // (The heuristic's lists for the plain and the bias epilogue of one shape hold the same
+      // solution indices in a different order, so nothing is gained by merging those two.)
       hipblasOperation_t op_first, op_second;
       PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_first, sizeof(op_first), nullptr));
       PDA_LT_CHECK(hipblasLtMatmulDescGetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_second, sizeof(op_second), nullptr));
       std::vector<hipblasLtMatmulHeuristicResult_t> all;
       if (hipblaslt_ext::getAllAlgos(handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, op_first, op_second, HIP_R_16BF,
                                      HIP_R_16BF, HIP_R_16BF, HIP_R_16BF, HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS) {
-        std::vector<int> have;
-        for (auto& f : found) have.push_back(hipblaslt_ext::getIndexFromAlgo(f.algo));
-        for (auto& cand : all) {
-          const int idx = hipblaslt_ext::getIndexFromAlgo(cand.algo);
-          if (std::find(have.begin(), have.end(), idx) != have.end()) continue;
-          if (!supported(cand.algo)) continue;
-          cand.state = HIPBLAS_STATUS_SUCCESS;
-          cand.workspaceSize = 0;  // checked against the limit by supported()
-          found.push_back(cand);
-          have.push_back(idx);
-        }
+        for (auto& cand : all)
+          if (supported(cand.algo)) add(cand.algo);
       }
-      p.candidates = (int)found.size();
     }
-    if (found.size() == 1) return;
+    p.candidates = (int)cands.size();
+    if (cands.size() == 1) return;
 
     hipEvent_t e0, e1;
     PDA_HIP_CHECK(hipEventCreate(&e0));
     PDA_HIP_CHECK(hipEventCreate(&e1));
     auto time_us = [&](int i, int runs) {
       PDA_HIP_CHECK(hipEventRecord(e0, stream));
-      for (int r = 0; r < runs; ++r) launch(handle, p, found[i].algo, a, b, out, ws, stream);
+      for (int r = 0; r < runs; ++r) launch(handle, p, cands[i], a, b, out, ws, stream);
       PDA_HIP_CHECK(hipEventRecord(e1, stream));
       PDA_HIP_CHECK(hipEventSynchronize(e1));
       float ms = 0.f;
       PDA_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
       return ms * 1e3f / runs;
     };
-    // Pass 1: every valid candidate; one run first, and the full measurement only for those within
-    // reach of the leader (an exhaustive list is mostly kernels several times too slow).
+    // Pass 1: every valid candidate: a validity run, one timed run, and the full measurement only
+    // for those within reach of the leader (an exhaustive list is mostly kernels several times too
+    // slow). The first candidate gets the same two runs before its measurement as all the others:
+    // the first touches of the operands (page tables, caches) otherwise land on its clock — which
+    // made the heuristic's own first choice look 10-30 % slower than it is.
     std::vector<std::pair<float, int>> timed;
     float leader = 1e30f;
-    for (int i = 0; i < (int)found.size(); ++i) {
-      if (found[i].state != HIPBLAS_STATUS_SUCCESS || found[i].workspaceSize > workspace_limit) continue;
-      // warm-up run doubles as the validity check of the candidate
-      hipblasStatus_t st = hipblasLtMatmul(handle, p.desc, &alpha, b.data_ptr(), p.la, a.data_ptr(), p.lb, &beta,
-                                           out.data_ptr(), p.lo, out.data_ptr(), p.lo, &found[i].algo, ws,
-                                           workspace_limit, stream);
-      if (st != HIPBLAS_STATUS_SUCCESS) continue;
+    for (int i = 0; i < (int)cands.size(); ++i) {
+      if (try_launch(handle, p, cands[i], a, b, out, ws, stream) != HIPBLAS_STATUS_SUCCESS) continue;
       float us = time_us(i, 1);
       if (i == 0 || us <= 1.25f * leader) us = time_us(i, timed_runs);
       if (i == 0) p.first_us = us;
@@ -411,7 +377,7 @@ class Planner {
       // in alternation and the lowest total wins.
       std::sort(timed.begin(), timed.end());
       std::vector<std::pair<float, int>> finalists;
-      const size_t keep = exhaustive ? 8 : 4;
+      const size_t keep = exhaustive ? 8 : 5;
       for (const auto& t : timed)
         if (finalists.size() < keep && t.first <= timed[0].first * 1.05f) finalists.emplace_back(0.f, t.second);
       if (finalists.size() > 1) {
@@ -422,9 +388,7 @@ class Planner {
       } else {
         best = timed[0].first;
       }
-      p.chosen = finalists[0].second;
-      p.algo = found[p.chosen].algo;
-      p.solution = hipblaslt_ext::getIndexFromAlgo(p.algo);
+      adopt(cands[finalists[0].second], finalists[0].second, (int)cands.size());
     }
     p.best_us = best;
     (void)hipEventDestroy(e0);

@@ -80,20 +80,9 @@ def planned_mm(a: torch.Tensor, b: torch.Tensor, *, trans_b: bool = False, bias=
 # (device, tokens, out, in) -> route of the input-gradient GEMM chosen by timing on this device:
 #   0  direct layout (contraction over the weight's row index)
 #   1  transpose the weight, then the contraction-contiguous GEMM
-#   2  as 1, issued with the bias epilogue and a zero bias: the library's kernels are specialised
-#      per epilogue, and for some shapes the bias family holds a faster kernel than the plain one
-#      (m=32768 n=5120 k=1280 on MI355X: 313 us against 358 us)
+# (Within each route the planner also tries the library's bias-epilogue kernels with a zero bias.)
 _DGRAD_TRANSPOSED: dict = {}
 _DGRAD_MIN_TOKENS = 2048
-_ZERO_BIAS: dict = {}
-
-
-def _zero_bias(n: int, device) -> torch.Tensor:
-    key = (device, n)
-    z = _ZERO_BIAS.get(key)
-    if z is None:
-        z = _ZERO_BIAS[key] = torch.zeros(n, dtype=torch.bfloat16, device=device)
-    return z
 
 
 def _time_us(fn, runs: int = 3) -> float:
@@ -126,23 +115,18 @@ def input_grad_mm(dy2: torch.Tensor, weight: torch.Tensor, dy_padded: torch.Tens
         return direct()
     ext = _ext.require()
     transposed = lambda: planned_mm(a, ext.transpose_2d(weight, pad_to), trans_b=True)  # noqa: E731
-    with_bias = lambda: planned_mm(a, ext.transpose_2d(weight, pad_to), trans_b=True,  # noqa: E731
-                                   bias=_zero_bias(K, weight.device))
-    routes = (direct, transposed, with_bias)
+    routes = (direct, transposed)
     key = (weight.device.index, M, N, K)
     choice = _DGRAD_TRANSPOSED.get(key)
     if choice is None:
         if torch.cuda.is_current_stream_capturing():
             return direct()  # cannot time inside a graph capture; decided by an eager step
         # two alternating measurements of each route; an extra kernel has to pay for itself clearly
-        totals = [0.0, 0.0, 0.0]
+        totals = [0.0, 0.0]
         for _ in range(2):
             for i, route in enumerate(routes):
                 totals[i] += _time_us(route)
-        choice = 0
-        for i in (1, 2):
-            if totals[i] < 0.99 * totals[choice]:
-                choice = i
+        choice = 1 if totals[1] < 0.99 * totals[0] else 0
         _DGRAD_TRANSPOSED[key] = choice
     return routes[int(choice)]()
 
