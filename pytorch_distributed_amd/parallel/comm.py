@@ -65,12 +65,14 @@ def _self_test(comm, device: torch.device) -> None:
     comm.reduce_scatter(part, wide, "avg", 1).wait()
     b = torch.full((n,), float(r), device=device)
     comm.broadcast(b, w - 1, 0).wait()
+    top = torch.tensor([float(r)], dtype=torch.float64, device=device)  # what timing code uses: float64 MAX
+    comm.all_reduce(top, "max", 1).wait()
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     ok = (bool((a == w * (w + 1) / 2).all())
           and bool((gathered.view(w, n).float() == torch.arange(w, device=device).view(w, 1)).all())
           and bool(torch.allclose(part, torch.full_like(part, r + (w - 1) / 2)))
-          and bool((b == w - 1).all()))
+          and bool((b == w - 1).all()) and float(top.item()) == w - 1)
     if not ok:
         raise RuntimeError("communicator self-test: a collective returned wrong values")
 
@@ -111,9 +113,10 @@ def _verified_native(create, device, probe_timeout_s: float):
         return comm
     if comm is not None:
         try:
-            comm.abort()
+            comm.abort()  # a collective the helper thread is still blocked in raises now
         except Exception:  # noqa: BLE001
             pass
+    t.join(20)  # let the helper unwind before anything else happens on this process
     return None
 
 

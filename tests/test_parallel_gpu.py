@@ -95,3 +95,20 @@ def test_fsdp_single_gpu_rccl_matches_plain(pg, strategy, reduce_fp32):
     if strategy != "NO_SHARD":
         assert sum(u.num_allgathers for u in units) > 0
     assert sum(u.num_reductions for u in units) == 4 * len(units)
+
+
+def test_fabric_measurement_and_self_test_run_on_the_rccl_communicator(pg):
+    """The start-up pieces a multi-GPU job runs before training — the communicator self-test and the
+    message-size ladder of the autotuner — on the real RCCL communicator (one rank: the collectives
+    are copies, but the streams, fences, in-place reduce-scatter / all-gather views and the float64
+    MAX are the ones used at any world size)."""
+    from pytorch_distributed_amd.parallel import autotune, comm
+
+    c = comm.get_communicator()
+    comm._self_test(c, torch.device("cuda", 0))
+    m = autotune.measure(c, torch.device("cuda", 0), ladder_mb=(1, 16), iters=3)
+    assert set(m) == {"all_reduce", "rs_ag", "all_gather"}
+    for rows in m.values():
+        assert len(rows) == 2 and all(t > 0 for _, t in rows)
+    policy = autotune.choose_policy(m, total_grad_bytes=1 << 30)
+    assert policy.ddp_bucket_mb > 0 and policy.fits
