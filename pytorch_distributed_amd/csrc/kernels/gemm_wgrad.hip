@@ -5,8 +5,11 @@
 // index as their ROW index, and the output (I x J = a weight matrix) has far fewer
 // 256 x 256 tiles than the chip has CUs (25-100 for GPT-2 Large), so the shape needs
 // split-K and transposed operand access at once. Here:
-//   * a workgroup (8 waves) owns one 256 x 256 output tile and one slice of M, so
-//     tiles x slices ~ 2 x 256 workgroups fill the 256 CUs twice over;
+//   * a workgroup owns one 256 x 256 output tile and one slice of M, so tiles x slices ~ 2 x 256
+//     workgroups fill the 256 CUs twice over. Two kernels share everything below: the default
+//     splits the tile over 4 waves of 128 x 128 (accumulators in the AGPR file, LDS reads and
+//     global loads issued in the shadow of the MFMAs by an explicit schedule), the older one over
+//     8 waves of 128 x 64 (PDA_WGRAD_WAVES=8; 11-13 % slower on GPT-2 shapes);
 //   * both operand tiles are staged as they lie in memory — 64 rows of M x 256 columns,
 //     fully coalesced 512-byte rows — and the MFMA fragments are read TRANSPOSED out of LDS
 //     with ds_read_b64_tr_b16, so no transpose pass and no strided global access exists;
@@ -29,6 +32,8 @@
 #include "attention_common.h"
 #include "pda_kernels.h"
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace pda {
 namespace {
@@ -322,6 +327,227 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
   }
 }
 
+// ---- four-wave variant ---------------------------------------------------------------------
+// Same tile, ring, swizzle and task mapping, but the 256 x 256 tile is split over 2 x 2 waves of
+// 128 x 128 each (16 accumulator tiles = 256 accumulator registers per lane, the whole AGPR
+// file): a k-step then needs 8 fragments (16 transposed reads) for 16 MFMAs instead of 6 for 8,
+// i.e. a third less LDS traffic per MFMA, and half as many waves meet at each barrier. One wave
+// per SIMD means nothing hides latency but the schedule itself: fragments of the next k-step are
+// always requested before the MFMAs of the current one are issued.
+constexpr int kThreads4 = 256;
+
+template <int kUnused>
+__global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __restrict__ A, int64_t lda,
+                                                           const bf16_raw* __restrict__ B, int64_t ldb,
+                                                           float* __restrict__ c_partial,
+                                                           float* __restrict__ bias_partial, int M, int I,
+                                                           int J, int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;  // 2 x 2 waves: 128 (i) x 128 (j) per wave
+  const int h = lane >> 5, r = lane & 31;
+
+  const int tiles_j = (J + kTile - 1) / kTile, tiles_i = (I + kTile - 1) / kTile;
+  const int n_tiles = tiles_i * tiles_j;
+  const int n_tasks = n_tiles * S;
+  const int q8 = n_tasks / 8, r8 = n_tasks % 8;
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int task = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+  const int slice = task / n_tiles;
+  const int tile = task % n_tiles;
+  const int ti = tile / tiles_j, tj = tile % tiles_j;
+
+  const int steps_total = M / kBM;
+  const int step_lo = int(int64_t(steps_total) * slice / S);
+  const int step_hi = int(int64_t(steps_total) * (slice + 1) / S);
+  const int n_steps = step_hi - step_lo;
+  if (n_steps <= 0) return;  // never true (S <= steps); tells the compiler the loop runs, so no path merges
+                             // 256 zero accumulators with the loop's results in ordinary registers
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  const bool do_bias = bias_partial != nullptr && tj == 0;  // workgroup-uniform
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  const unsigned smem_base = lds_addr(smem);
+  unsigned a_base[4], b_base[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) a_base[a] = frag_base(wi * 4 + a, lane);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) b_base[b] = frag_base(wj * 4 + b, lane);
+  const unsigned bias_off = (unsigned)wg_tile_off(tid >> 5, tid & 31);  // rows 0..7; +8 rows: +4096 bytes
+
+  // Each wave plays two of the eight "row pair" roles of the eight-wave kernel (wave, wave + 4).
+  // Loads of one stage per wave, oldest first: A rows 0-15 (2), B rows 0-15 (2), A rows 16-31 (2),
+  // B rows 16-31 (2): the first four are k-step 0.
+  // The four roles of a wave differ by 8 q + 16 half rows, a multiple of 4: the swizzle (row & 3) and
+  // with it the per-lane column are the same for all of them, so ONE per-lane pointer per operand
+  // serves every load and the rest of the address is wave-uniform.
+  const bf16_raw* a_src = stage_src(A, lda, step_lo * kBM, ti * kTile, I, 0, wave, lane);
+  const bf16_raw* b_src = stage_src(B, ldb, step_lo * kBM, tj * kTile, J, 0, wave, lane);
+  const int64_t a_stride = int64_t(kBM) * lda, b_stride = int64_t(kBM) * ldb;
+  // Load `i` (0..7) of stage t into ring slot `slot_idx`; issue order = age order:
+  // A rows 0-15 (2 loads), B rows 0-15 (2), A rows 16-31 (2), B rows 16-31 (2).
+  auto issue_one = [&](int t, int slot_idx, int i) {
+    char* slot = smem + slot_idx * kStageBytes;
+    const int half = i >> 2, is_b = (i >> 1) & 1, q = i & 1;
+    const int64_t rows = int64_t(t < n_steps ? t : n_steps - 1) * kBM + 16 * half + 8 * q;  // wave-uniform
+    if (is_b) stage_half(b_src + rows * ldb, slot + kTileBytes, half, wave + 4 * q);
+    else stage_half(a_src + rows * lda, slot, half, wave + 4 * q);
+  };
+  // Every stage issues exactly 8 loads per wave — past the end of the slice they re-fetch its last
+  // rows into a slot nobody reads any more — so the counted waits are the same in every iteration
+  // and the loop body has no branch that would cut its MFMA sequences into separate blocks.
+#pragma unroll
+  for (int t = 0; t < kStages - 1; ++t)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_one(t, t, i);
+
+  // Fragment registers: set 0 = k-step 0 of the stage being multiplied (requested a stage ahead),
+  // set 1 = its k-step 1 (requested under the MFMAs of k-step 0).
+  s16x4 al[2][4], ah[2][4], bl[2][4], bh[2][4];
+  // Transposed read number `i` (0..15) of k-step `ks` from the stage in ring slot `slot_idx`.
+  auto frag_read = [&](int set, int ks, int slot_idx, int i) {
+    const unsigned a_tile = smem_base + slot_idx * kStageBytes;
+    const unsigned b_tile = a_tile + kTileBytes;
+    const int x = (i >> 1) & 3;
+    if (ks == 0) {
+      if (i < 8) { if (i & 1) ah[set][x] = tr_read<4096>(a_tile + a_base[x]); else al[set][x] = tr_read<0>(a_tile + a_base[x]); }
+      else       { if (i & 1) bh[set][x] = tr_read<4096>(b_tile + b_base[x]); else bl[set][x] = tr_read<0>(b_tile + b_base[x]); }
+    } else {
+      if (i < 8) { if (i & 1) ah[set][x] = tr_read<12288>(a_tile + a_base[x]); else al[set][x] = tr_read<8192>(a_tile + a_base[x]); }
+      else       { if (i & 1) bh[set][x] = tr_read<12288>(b_tile + b_base[x]); else bl[set][x] = tr_read<8192>(b_tile + b_base[x]); }
+    }
+  };
+  {
+    // k-step 0 of stage 0: this wave's first four loads, then everyone's.
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) frag_read(0, 0, 0, i);
+  }
+
+  auto main_loop = [&](auto with_bias) {
+    constexpr bool kBias = decltype(with_bias)::value;
+    for (int t0 = 0; t0 < n_steps; t0 += kStages) {
+#pragma unroll
+      for (int u = 0; u < kStages; ++u) {
+        const int t = t0 + u;
+        if (t >= n_steps) break;  // workgroup-uniform
+        // Stage t complete and k-step 0 of stage t+1 landed; the 12 younger loads stay in flight.
+        // This wave's k-step 0 fragments (requested a stage ago) are awaited here as well, so that
+        // the matrix pipe starts the moment the barrier opens.
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned a_tile = smem_base + u * kStageBytes;
+
+        // ---- k-step 0: 16 MFMAs; in their shadow the 16 fragment reads of k-step 1 (two after
+        // each of the first eight), then the 8 global loads that refill the slot the barrier freed.
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          af[x] = join(al[0][x], ah[0][x]);
+          bfr[x] = join(bl[0][x], bh[0][x]);
+        }
+        u32x4 bias_rows[4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          acc[i >> 2][i & 3] = mfma32(af[i >> 2], bfr[i & 3], acc[i >> 2][i & 3]);
+          if (i < 8) {
+            frag_read(1, 1, u, 2 * i);
+            frag_read(1, 1, u, 2 * i + 1);
+          } else {
+            issue_one(t + kStages - 1, (u + kStages - 1) % kStages, i - 8);
+          }
+          if (kBias) {  // column sums of the A tile: chunk (tid & 31) of rows (tid >> 5) + 8 j
+            if (i == 8) bias_rows[0] = b128_read<0>(a_tile + bias_off);
+            if (i == 9) bias_rows[1] = b128_read<4096>(a_tile + bias_off);
+            if (i == 10) bias_rows[2] = b128_read<8192>(a_tile + bias_off);
+            if (i == 11) bias_rows[3] = b128_read<12288>(a_tile + bias_off);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // k-step 1 fragments (and the bias rows)
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- k-step 1: 16 MFMAs; in their shadow the fragment reads of k-step 0 of stage t+1
+        // (landed before this stage's barrier; after the last stage they fetch stale bytes that
+        // nothing uses).
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          af[x] = join(al[1][x], ah[1][x]);
+          bfr[x] = join(bl[1][x], bh[1][x]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          acc[i >> 2][i & 3] = mfma32(af[i >> 2], bfr[i & 3], acc[i >> 2][i & 3]);
+          if (i < 8) {
+            frag_read(0, 0, (u + 1) % kStages, 2 * i);
+            frag_read(0, 0, (u + 1) % kStages, 2 * i + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kBias) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              bsum[2 * w] += bf16_lo(bias_rows[i][w]);
+              bsum[2 * w + 1] += bf16_hi(bias_rows[i][w]);
+            }
+        }
+      }
+    }
+  };
+  if (do_bias) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy loads
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // the ring is reused below
+
+  // One accumulator tile at a time leaves the accumulator file (the fences keep the compiler from
+  // moving all 256 values into ordinary registers at once, which it can only do by spilling).
+  float* cp = c_partial + (int64_t(slice) * I + int64_t(ti) * kTile) * J + int64_t(tj) * kTile;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x16 tile_vals = acc[a][b];
+      asm volatile("" : "+v"(tile_vals));
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * (4 * wi + a) + acc_row(e, h);
+        const int j = 32 * (4 * wj + b) + r;
+        if (ti * kTile + i < I && tj * kTile + j < J) cp[int64_t(i) * J + j] = tile_vals[e];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+  if (do_bias) {  // fold the 8 threads that share a chunk (same tid & 31) through LDS
+    float* red = reinterpret_cast<float*>(smem);  // [8][256]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 5) * kTile + (tid & 31) * 8 + e] = bsum[e];
+    __syncthreads();
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += red[g * kTile + tid];
+      if (ti * kTile + tid < I) bias_partial[int64_t(slice) * I + ti * kTile + tid] = s;
+    }
+  }
+}
+
 // out[n] (+)= sum_s partial[s][n], n over `numel` elements, 4 per thread. The last
 // `bias_blocks` workgroups of the grid do the same for the (much smaller) bias partials, so a
 // linear layer's weight and bias gradients are folded by one launch (each written or added
@@ -390,13 +616,21 @@ bool wgrad_supported(int M, int I, int J) {
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream) {
   const int n_tasks = ((I + kTile - 1) / kTile) * ((J + kTile - 1) / kTile) * S;
-  static int mode = -1;
+  static int mode = -1, waves = 4;
   if (mode < 0) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    const char* w = getenv("PDA_WGRAD_WAVES");  // 8 selects the eight-wave kernel (A/B measurements)
+    waves = w ? atoi(w) : 4;
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     const char* e = getenv("PDA_WGRAD_MODE");
     mode = e ? atoi(e) : 0;
+  }
+  if (waves == 4 && mode == 0) {
+    hipLaunchKernelGGL(wgrad_kernel4<0>, dim3((unsigned)n_tasks), dim3(kThreads4), kStages * kStageBytes, stream,
+                       (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
+    return;
   }
   auto kern = mode == 1 ? wgrad_kernel<1> : mode == 2 ? wgrad_kernel<2> : wgrad_kernel<0>;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(kThreads), kStages * kStageBytes, stream,
