@@ -30,14 +30,23 @@
 //
 // Needs K % 32 == 0 and N % 8 == 0; M is arbitrary (edge rows are clamped on load, masked on store).
 //
-// Measured (MI355X, 32768 x 5120 x 1280): 583 us for GEMM + bias = 0.74 PFLOP/s against 313 us for
-// the library's tuned algorithm, and 941 us with the GELU epilogue. Two known causes: a stage row is
-// 64 bytes, so every LDS-DMA request uses half of a 128-byte line, and the register-direct
-// epilogue writes 16 contiguous bytes per row and instruction. The Python side therefore keeps
-// this kernel opt-in (ops/mlp.py).
+// Measured (MI355X, 32768 x 5120 x 1280, one box; library = hipBLASLt's tuned algorithm):
+//                          library (+ GELU kernel)   eight-wave kernel   four-wave persistent kernel
+//   GEMM + bias                  306 us                   583 us                405 us
+//   GEMM + bias, u and gelu(u)   439 us                   941 us                499 us
+//   GEMM * gelu'(u)              508 us                     -                   489 us
+// The four-wave kernel's main loop runs at ~1.15 PFLOP/s (library: 1.4). What keeps the fused forms
+// from paying: the activation is ~9 VALU operations and two transcendentals per element — about
+// 77 us of the whole chip's vector throughput for this tensor — and in an epilogue that work runs
+// while the matrix pipe of the same CU waits, whereas the stand-alone kernel hides it under its own
+// memory traffic. Overlapping it needs producer / consumer wave specialisation (MFMA waves and
+// epilogue waves on one CU), which this kernel does not have. A staggered start of the persistent
+// workgroups (to spread the store bursts) was measured and changed nothing. The Python side
+// therefore keeps these kernels opt-in (ops/mlp.py).
 #include "attention_common.h"
 #include "gelu_math.h"
 #include "pda_kernels.h"
+#include <stdlib.h>
 
 namespace pda {
 namespace {
@@ -250,6 +259,217 @@ __global__ __launch_bounds__(kThreads) void gemm_fused_kernel(const bf16_raw* __
   }
 }
 
+
+// ---- four-wave kernel ------------------------------------------------------------------------
+// Same ring, slabs and swizzle, restructured like the four-wave weight-gradient kernel: 2 x 2 waves
+// of 128 x 128 each (16 accumulator tiles in the AGPR file; a k-step needs 8 fragment reads for 16
+// MFMAs instead of 6 for 8), a branch-free stage body in which the fragment reads of the next
+// k-step and the global loads that refill the ring are issued in the shadow of the MFMAs, and an
+// epilogue that goes through LDS: the finished tile is written as bf16 into the (now idle) ring,
+// XOR-swizzled, and leaves in full 512-byte rows — 16 bytes per lane — where the bias, the
+// activation and the second output are applied. Needs M % 256 == 0 and N % 256 == 0 (one per-lane
+// source pointer per operand, no edge handling).
+constexpr int kThreads4 = 256;
+constexpr int kOutRowBytes = kTile * 2;  // a staged output row: 256 bf16
+
+__device__ __forceinline__ void load_piece_at(const bf16_raw* src, char* slab, int row) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(slab + row * kRowBytes), 16, 0, 0);
+}
+
+template <int kEpi>
+__global__ __launch_bounds__(kThreads4) void gemm_fused_kernel4(const bf16_raw* __restrict__ X, int64_t ldx,
+                                                                const bf16_raw* __restrict__ W, int64_t ldw,
+                                                                const bf16_raw* __restrict__ bias,
+                                                                bf16_raw* __restrict__ out, int64_t ldo,
+                                                                bf16_raw* __restrict__ aux, int64_t ldaux, int M, int N,
+                                                                int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;  // 2 (tokens) x 2 (features) waves: 128 x 128 per wave
+  const int r = lane & 31, kg = lane >> 5;
+
+  // Persistent workgroups: the grid is at most one workgroup per CU and each walks its share of the
+  // tiles. The global stores of a finished tile are only ISSUED by its epilogue; they drain while
+  // the same workgroup is already loading and multiplying its next tile, so the output traffic
+  // overlaps the matrix pipe instead of stopping it once per tile on all CUs at the same time.
+  // Workgroup ids are dealt round-robin to the 8 XCDs: XCD x owns the contiguous task range
+  // [lo, hi) and its workgroups stride through it together.
+  const int tiles_m = M / kTile, tiles_n = N / kTile;
+  const int n_tasks = tiles_m * tiles_n;
+  const int q8 = n_tasks / 8, r8 = n_tasks % 8;
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int per_xcd = (int(gridDim.x) + 7 - xcd) / 8;  // workgroups of this launch that sit on this XCD
+  const int lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int hi = lo + (xcd < r8 ? q8 + 1 : q8);
+  const int n_steps = K / kBK;
+  if (n_steps <= 0) return;  // never true; removes the path that would merge 256 zero accumulators
+  const unsigned smem_base = lds_addr(smem);
+  const int f = (r >> 2) & 3;
+  const unsigned x_row = (unsigned)((128 * wi + r) * kRowBytes);
+  const unsigned w_row = (unsigned)(kTileBytes + (128 * wj + r) * kRowBytes);
+  const unsigned s0 = (unsigned)(((kg ^ f) & 3) << 4), s1 = (unsigned)((((2 + kg) ^ f) & 3) << 4);
+  const unsigned xa[2] = {x_row + s0, x_row + s1}, wa[2] = {w_row + s0, w_row + s1};
+  const int lrow = 64 * wave + (lane >> 2);
+  const int lchunk = (lane & 3) ^ ((lrow >> 2) & 3);
+
+  for (int task = lo + within; task < hi; task += per_xcd) {
+  const int group = task / (kGroupM * tiles_n);
+  const int in_group = task - group * (kGroupM * tiles_n);
+  const int group_rows = min(kGroupM, tiles_m - group * kGroupM);
+  const int tn = in_group / group_rows;
+  const int tm = group * kGroupM + in_group % group_rows;
+  const int m0 = tm * kTile, n0 = tn * kTile;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- staging: piece i (0..7) of a stage = rows 64*wave + 16*(i & 3) .. +15 of the X slab (i < 4)
+  // or of the W slab. The swizzle only looks at bits 2-3 of the row, which those offsets leave
+  // alone, so one per-lane pointer per operand serves all pieces.
+  const bf16_raw* x_src = X + int64_t(m0 + lrow) * ldx + lchunk * 8;
+  const bf16_raw* w_src = W + int64_t(n0 + lrow) * ldw + lchunk * 8;
+  auto issue_one = [&](int t, int slot_idx, int i) {
+    char* slot = smem + slot_idx * kStageBytes;
+    const int ko = (t < n_steps ? t : n_steps - 1) * kBK;  // past the end: re-fetch the last slab (never read)
+    const int rows = 16 * (i & 3);
+    if (i < 4) load_piece_at(x_src + (int64_t(rows) * ldx + ko), slot, 64 * wave + rows);
+    else load_piece_at(w_src + (int64_t(rows) * ldw + ko), slot + kTileBytes, 64 * wave + rows);
+  };
+#pragma unroll
+  for (int t = 0; t < kStages - 1; ++t)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_one(t, t, i);
+
+  // (fragment addresses: lane (r, kg) reads row r of a 32-row block, chunk 2*kstep + kg)
+  bf16x8 xf[2][4], wf[2][4];  // [k-step][32-row block]
+  // Fragment read i (0..7) of k-step ks: order x0 w0 w1 w2 w3 x1 x2 x3, the order the MFMAs need them.
+  auto frag = [&](int ks, unsigned base, int i) {
+    if (i == 0) xf[ks][0] = frag_read<0>(base + xa[ks]);
+    if (i == 1) wf[ks][0] = frag_read<0>(base + wa[ks]);
+    if (i == 2) wf[ks][1] = frag_read<2048>(base + wa[ks]);
+    if (i == 3) wf[ks][2] = frag_read<4096>(base + wa[ks]);
+    if (i == 4) wf[ks][3] = frag_read<6144>(base + wa[ks]);
+    if (i == 5) xf[ks][1] = frag_read<2048>(base + xa[ks]);
+    if (i == 6) xf[ks][2] = frag_read<4096>(base + xa[ks]);
+    if (i == 7) xf[ks][3] = frag_read<6144>(base + xa[ks]);
+  };
+
+  for (int t0 = 0; t0 < n_steps; t0 += kStages) {
+#pragma unroll
+    for (int u = 0; u < kStages; ++u) {
+      const int t = t0 + u;
+      if (t >= n_steps) break;  // workgroup-uniform
+      // Stage t landed (the 16 younger loads stay in flight); after the barrier everyone's part has,
+      // and everyone is done reading stage t-1, whose slot is refilled below.
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned base = smem_base + u * kStageBytes;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) frag(0, base, i);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 0: MFMA (a, b) needs x[a] and w[b]; the reads return in order, so the waits count
+      // down as the first row of products proceeds. In the shadow: the 8 reads of k-step 1, then
+      // the 8 global loads of stage t+3.
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        if (i == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // w1 (one k-step-1 read queued behind)
+        if (i == 2) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // w2
+        if (i == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // w3
+        if (i == 4) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // x1
+        if (i == 8) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // x2
+        if (i == 12) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");  // x3
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i >> 2][i & 3] = mfma32(wf[0][i & 3], xf[0][i >> 2], acc[i >> 2][i & 3]);
+        if (i < 8) frag(1, base, i);
+        else issue_one(t + kStages - 1, (u + kStages - 1) % kStages, i - 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[i >> 2][i & 3] = mfma32(wf[1][i & 3], xf[1][i >> 2], acc[i >> 2][i & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the tail's dummy loads
+  __syncthreads();  // the ring becomes the staging tile
+
+  // ---- epilogue, part 1: accumulators -> bf16 tile in LDS ---------------------------------------
+  // acc[a][b] register e of lane (r, h = kg): token 128*wi + 32*a + r, feature
+  // 128*wj + 32*b + 8*(e >> 2) + 4*h + (e & 3): a register quad is 4 consecutive features = 8 bytes.
+  // Staged row = token (512 bytes), 16-byte chunk index XOR (token & 31): the 32 lanes of a half-wave
+  // write 32 different rows at one feature offset -> 32 different chunk slots.
+  const int h = kg;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x16 v = acc[a][b];
+      asm volatile("" : "+v"(v));  // one tile at a time leaves the accumulator file
+      const int tok = 128 * wi + 32 * a + r;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int feat = 128 * wj + 32 * b + 8 * g + 4 * h;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (kEpi == kEpiBias || kEpi == kEpiBiasGelu) {
+          const u32x2 braw = *reinterpret_cast<const u32x2*>(bias + n0 + feat);
+          bv[0] = bf16_lo(braw[0]);
+          bv[1] = bf16_hi(braw[0]);
+          bv[2] = bf16_lo(braw[1]);
+          bv[3] = bf16_hi(braw[1]);
+        }
+        const u32x2 packed = pack4(v[4 * g] + bv[0], v[4 * g + 1] + bv[1], v[4 * g + 2] + bv[2], v[4 * g + 3] + bv[3]);
+        const int chunk = (feat >> 3) ^ (tok & 31);
+        *reinterpret_cast<u32x2*>(smem + tok * kOutRowBytes + chunk * 16 + (feat & 7) * 2) = packed;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  __syncthreads();
+
+  // ---- epilogue, part 2: full rows out; element-wise work on 8 features per lane -----------------
+  // Thread -> chunk (tid & 31) of rows (tid >> 5) + 8 i: a wave instruction moves two whole rows.
+  const int ch = tid & 31;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    const int tok = (tid >> 5) + 8 * i;
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + tok * kOutRowBytes + ((ch ^ (tok & 31)) << 4));
+    const int64_t m = m0 + tok;
+    const int n = n0 + ch * 8;
+    if constexpr (kEpi == kEpiMulGeluGrad) {
+      const u32x4 uraw = *reinterpret_cast<const u32x4*>(aux + m * ldaux + n);
+      u32x4 res;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        res[w] = pack_bf16x2(bf16_lo(raw[w]) * gelu_grad_f(bf16_lo(uraw[w])), bf16_hi(raw[w]) * gelu_grad_f(bf16_hi(uraw[w])));
+      *reinterpret_cast<u32x4*>(out + m * ldo + n) = res;
+    } else {
+      *reinterpret_cast<u32x4*>(out + m * ldo + n) = raw;
+      if constexpr (kEpi == kEpiBiasGelu) {
+        // the activation of the ROUNDED pre-activation: what the backward recomputes from `out`
+        u32x4 act;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) act[w] = pack_bf16x2(gelu_f(bf16_lo(raw[w])), gelu_f(bf16_hi(raw[w])));
+        *reinterpret_cast<u32x4*>(aux + m * ldaux + n) = act;
+      }
+    }
+  }
+  __syncthreads();  // every wave has read its rows out of LDS: the ring may be refilled
+  }  // next tile of this workgroup
+}
+
 }  // namespace
 
 bool gemm_fused_supported(int M, int N, int K) { return M >= 1 && K >= kBK && K % kBK == 0 && N >= 8 && N % 8 == 0; }
@@ -258,12 +478,41 @@ void gemm_fused(const void* X, int64_t ldx, const void* W, int64_t ldw, const vo
                 int64_t ldaux, int M, int N, int K, int epilogue, hipStream_t stream) {
   const int n_tasks = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
   static bool configured = false;
+  static int waves = 4;
   if (!configured) {
+    (void)hipFuncSetAttribute((const void*)gemm_fused_kernel4<kEpiNone>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)gemm_fused_kernel4<kEpiBias>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)gemm_fused_kernel4<kEpiBiasGelu>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)gemm_fused_kernel4<kEpiMulGeluGrad>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    const char* w = getenv("PDA_FUSED_GEMM_WAVES");  // 8 selects the eight-wave kernel (A/B measurements)
+    waves = w ? atoi(w) : 4;
     (void)hipFuncSetAttribute((const void*)gemm_fused_kernel<kEpiNone>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)gemm_fused_kernel<kEpiBias>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)gemm_fused_kernel<kEpiBiasGelu>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)gemm_fused_kernel<kEpiMulGeluGrad>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     configured = true;
+  }
+  if (waves == 4 && M % kTile == 0 && N % kTile == 0) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (cus <= 0) cus = 256;
+    }
+    const int grid4 = n_tasks < cus ? n_tasks : cus;  // one persistent workgroup per CU (128 KiB of LDS each)
+#define PDA_LAUNCH4(EPI)                                                                                             \
+  hipLaunchKernelGGL(gemm_fused_kernel4<EPI>, dim3((unsigned)grid4), dim3(kThreads4), kStages * kStageBytes, stream, \
+                     (const bf16_raw*)X, ldx, (const bf16_raw*)W, ldw, (const bf16_raw*)bias, (bf16_raw*)out, ldo,     \
+                     (bf16_raw*)aux, ldaux, M, N, K)
+    switch (epilogue) {
+      case kEpiNone: PDA_LAUNCH4(kEpiNone); break;
+      case kEpiBias: PDA_LAUNCH4(kEpiBias); break;
+      case kEpiBiasGelu: PDA_LAUNCH4(kEpiBiasGelu); break;
+      default: PDA_LAUNCH4(kEpiMulGeluGrad); break;
+    }
+#undef PDA_LAUNCH4
+    return;
   }
 #define PDA_LAUNCH(EPI)                                                                                              \
   hipLaunchKernelGGL(gemm_fused_kernel<EPI>, dim3((unsigned)n_tasks), dim3(kThreads), kStages * kStageBytes, stream,   \

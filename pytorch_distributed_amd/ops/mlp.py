@@ -14,12 +14,13 @@ Weight and bias gradients use the native weight-gradient kernel with gradient si
 ``ops.linear``.
 
 Status: OPT-IN (``PDA_FUSED_MLP=1``). Measured on MI355X at 32 K tokens, d = 1280
-(``tools/gemm_fused_probe.py``, ``profiles/r2/gemm_fused_probe.log``): the kernel's main loop runs at
-0.74 PFLOP/s where hipBLASLt's tuned algorithm reaches 1.37, and its register-direct epilogue
-(8-byte stores, 16 contiguous bytes per row and instruction) costs more than the stand-alone GELU
-kernel it replaces — 941 us fused against 457 us for library GEMM + GELU kernel. Until the kernel
-beats that pair, the default is the library GEMM with the stand-alone activation kernels (which run
-at the HBM roofline); the fused path stays available, tested, for further work on it.
+(``tools/gemm_fused_probe.py``, ``profiles/r2/gemm_fused_probe*.log``): with the four-wave persistent
+kernel the forward pair (u and gelu(u) from one GEMM) takes 499 us against 439 us for library GEMM +
+GELU kernel, the backward form (GEMM * gelu'(u)) 489 us against 508 us. The activation's arithmetic
+(~77 us of the chip's vector throughput per call) runs in the epilogue while the matrix pipe waits;
+the stand-alone kernels hide it under their memory traffic instead. Until the kernel overlaps the two
+(wave specialisation), the default is the library GEMM with the stand-alone activation kernels; the
+fused path stays available, tested, for further work on it.
 """
 from __future__ import annotations
 
