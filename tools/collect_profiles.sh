@@ -1,21 +1,32 @@
 #!/bin/bash
 # Collects the numbers quoted in profiles/README.md into gpurun_out/final (run on the GPU box).
+# Every GPU step runs under its own time limit and the script stops at the first failure.
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout -k 10 150 python bench.py --steps 8 --warmup 3 > $O/bench_single_mb32.json 2> $O/bench_single_mb32.err || exit 1
-timeout -k 10 150 python bench.py --steps 8 --warmup 3 --micro-batch 16 > $O/bench_single_mb16.json 2>> $O/bench_single_mb32.err || exit 1
-timeout -k 10 150 python bench.py --steps 8 --warmup 3 --wrap-single --mode fsdp > $O/bench_fsdp_world1.json 2>> $O/bench_single_mb32.err || exit 1
-timeout -k 10 150 python bench.py --steps 8 --warmup 3 --wrap-single --mode ddp > $O/bench_ddp_world1.json 2>> $O/bench_single_mb32.err || exit 1
+B="python bench.py --steps 10 --warmup 3"
+TR="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
+timeout -k 10 150 $B > $O/bench_large_single_mb32.json 2> $O/bench.err || exit 1
+timeout -k 10 150 $B --activation-checkpoint selective > $O/bench_large_single_mb32_selective.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --activation-checkpoint full > $O/bench_large_single_mb32_full.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --micro-batch 8 > $O/bench_large_single_mb8_dropout0.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --micro-batch 8 --dropout 0.1 > $O/bench_large_single_mb8_dropout0.1.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --model gpt2-medium > $O/bench_medium_single.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --model gpt2 > $O/bench_small_single.json 2>> $O/bench.err || exit 1
+timeout -k 10 200 $B --model gpt2-xl > $O/bench_xl_single.json 2>> $O/bench.err || exit 1
+timeout -k 10 250 $TR --master-port 29751 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both > $O/bench_large_world1_forced_ddp_fsdp.json 2>> $O/bench.err || exit 1
+timeout -k 10 250 $TR --master-port 29752 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both --model gpt2-medium > $O/bench_medium_world1_forced_ddp_fsdp.json 2>> $O/bench.err || exit 1
 timeout -k 10 100 python tools/wgrad_probe.py > $O/wgrad_probe.log 2>&1 || exit 1
-timeout -k 10 100 python tools/lt_probe.py > $O/gemm_planner_probe.log 2>&1 || exit 1
+PDA_WGRAD_WAVES=8 timeout -k 10 100 python tools/wgrad_probe.py > $O/wgrad_probe_eight_wave.log 2>&1 || exit 1
 timeout -k 10 60 python tools/attn_time.py > $O/attention_time.log 2>&1 || exit 1
-timeout -k 10 60 ./tools/micro/mfma_peak > $O/mfma_peak.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 4 --warmup 3 > $O/prof.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_attn -- python3 $R/tools/attn_pmc.py > $O/pmc_attn.log 2>&1 || exit 1
+python3 $R/tools/step_breakdown.py $O/prof/*/*_kernel_trace.csv 3 > $O/step_breakdown.txt || exit 1
+cp $O/prof/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+rm -rf $O/prof
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_wgrad -- python3 $R/tools/wgrad_pmc.py > $O/pmc_wgrad.log 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/pmc_wgrad_l2 -- python3 $R/tools/wgrad_pmc.py > $O/pmc_wgrad_l2.log 2>&1 || exit 1
+python3 $R/tools/pmc_summary.py $O/pmc_wgrad > $O/pmc_wgrad_summary.txt 2>&1
+rm -rf $O/pmc_wgrad
 echo collected
