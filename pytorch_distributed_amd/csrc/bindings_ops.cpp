@@ -417,9 +417,12 @@ bool wgrad_supported(int64_t M, int64_t I, int64_t J) { return pda::wgrad_suppor
 // dW[I, J] = dy[M, I]^T . x[M, J] and (optionally) db[I] = column sums of dy, both bf16.
 // With `out` the weight gradient is written into that tensor (a slice of a reducer's flat
 // gradient buffer) instead of a fresh one — added to its contents when `accumulate` is set.
+// `out_rows` (default: all I): only the leading rows of dW are produced — for a dy whose trailing
+// columns are zero padding (the LM head's logits gradient, V = 50257 in a 50304-column buffer).
 std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, bool want_bias,
                                      const std::optional<at::Tensor>& out, bool accumulate,
-                                     const std::optional<at::Tensor>& bias_out, bool bias_accumulate) {
+                                     const std::optional<at::Tensor>& bias_out, bool bias_accumulate,
+                                     int64_t out_rows) {
   TORCH_CHECK(dy.is_cuda() && x.is_cuda() && dy.dim() == 2 && x.dim() == 2, "wgrad: 2-D GPU tensors");
   TORCH_CHECK(dy.scalar_type() == at::kBFloat16 && x.scalar_type() == at::kBFloat16, "wgrad: bf16 only");
   TORCH_CHECK(dy.stride(1) == 1 && x.stride(1) == 1, "wgrad: rows must be contiguous");
@@ -430,6 +433,9 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
                   reinterpret_cast<uintptr_t>(dy.data_ptr()) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
               "wgrad: operands must be 16-byte aligned with row strides that are multiples of 8");
+  if (out_rows < 0) out_rows = I;
+  TORCH_CHECK(out_rows >= 1 && out_rows <= I && (out_rows * J) % 4 == 0, "wgrad: bad out_rows ", out_rows);
+  TORCH_CHECK(out_rows == I || !want_bias, "wgrad: out_rows and the bias gradient are not combined");
   const c10::DeviceGuard guard(dy.device());
   const int S = pda::wgrad_pick_slices((int)M, (int)I, (int)J);
   auto f32 = dy.options().dtype(at::kFloat);
@@ -442,12 +448,12 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
   at::Tensor dw;
   if (out.has_value()) {
     dw = *out;
-    TORCH_CHECK(dw.is_cuda() && dw.is_contiguous() && dw.numel() == I * J &&
+    TORCH_CHECK(dw.is_cuda() && dw.is_contiguous() && dw.numel() == out_rows * J &&
                     (dw.scalar_type() == at::kBFloat16 || dw.scalar_type() == at::kFloat),
-                "wgrad: out must be a contiguous bf16/fp32 GPU tensor with ", I * J, " elements");
+                "wgrad: out must be a contiguous bf16/fp32 GPU tensor with ", out_rows * J, " elements");
   } else {
     TORCH_CHECK(!accumulate, "wgrad: accumulate needs an out tensor");
-    dw = at::empty({I, J}, dy.options());
+    dw = at::empty({out_rows, J}, dy.options());
   }
   at::Tensor db;
   if (want_bias) {
@@ -461,7 +467,7 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
       db = at::empty({I}, dy.options());
     }
   }
-  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, dtype_of(dw), dw.data_ptr(), accumulate,
+  pda::wgrad_reduce(partial.data_ptr<float>(), S, out_rows * J, I * J, dtype_of(dw), dw.data_ptr(), accumulate,
                     want_bias ? bpartial.data_ptr<float>() : nullptr, I, want_bias ? dtype_of(db) : pda::kBF16,
                     want_bias ? db.data_ptr() : nullptr, want_bias && bias_accumulate, stream);
   check_launch("wgrad_reduce");
@@ -615,7 +621,7 @@ void bind_ops(py::module_& m) {
   m.def("wgrad_supported", &wgrad_supported);
   m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"),
         py::arg("out") = py::none(), py::arg("accumulate") = false, py::arg("bias_out") = py::none(),
-        py::arg("bias_accumulate") = false);
+        py::arg("bias_accumulate") = false, py::arg("out_rows") = -1);
   m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
         py::arg("bias"), py::arg("eps"), py::arg("rms"), py::arg("dropout_p") = 0.0, py::arg("seed") = 0);
   m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"),

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
 // to its destination, which may be a slice of a reducer's flat gradient buffer).
 template <typename OutT, typename BiasT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int S,
-                                                           int64_t numel, OutT* __restrict__ out,
+                                                           int64_t numel, int64_t slice_stride, OutT* __restrict__ out,
                                                            bool accumulate, const float* __restrict__ bias_partial,
                                                            int64_t bias_numel, BiasT* __restrict__ bias_out,
                                                            bool bias_accumulate, int bias_blocks) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int64_t n = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 4; n < numel; n += stride) {
     f32x4 s = *reinterpret_cast<const f32x4*>(partial + n);
     for (int k = 1; k < S; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(partial + int64_t(k) * numel + n);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(partial + int64_t(k) * slice_stride + n);
       s += v;
     }
 #pragma unroll
@@ -637,7 +637,7 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
                      (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
 }
 
-void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
+void wgrad_reduce(const float* partial, int S, int64_t numel, int64_t slice_stride, DType out_dtype, void* out, bool accumulate,
                   const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
                   bool bias_accumulate, hipStream_t stream) {
   int64_t blocks = ceil_div(numel, 1024);
@@ -646,7 +646,7 @@ void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, v
   const dim3 grid((unsigned)(blocks + bias_blocks));
 #define PDA_REDUCE(OUT_T, BIAS_T)                                                                             \
   hipLaunchKernelGGL((wgrad_reduce_kernel<OUT_T, BIAS_T>), grid, dim3(256), 0, stream, partial, S, numel,       \
-                     (OUT_T*)out, accumulate, bias_partial, bias_numel, (BIAS_T*)bias_out, bias_accumulate, \
+                     slice_stride, (OUT_T*)out, accumulate, bias_partial, bias_numel, (BIAS_T*)bias_out, bias_accumulate, \
                      bias_blocks)
   if (out_dtype == kBF16) {
     if (bias_dtype == kBF16) PDA_REDUCE(bf16_raw, bf16_raw); else PDA_REDUCE(bf16_raw, float);

@@ -126,8 +126,10 @@ bool wgrad_supported(int M, int I, int J);
 int wgrad_pick_slices(int M, int I, int J);
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream);
+// Folds the first `numel` elements of every slice (slices `slice_stride` elements apart; numel ==
+// slice_stride for a whole result, smaller when only the leading rows of C are wanted).
 // bias_partial (optional, [S][bias_numel]) is folded into bias_out (bf16) by the same launch.
-void wgrad_reduce(const float* partial, int S, int64_t numel, DType out_dtype, void* out, bool accumulate,
+void wgrad_reduce(const float* partial, int S, int64_t numel, int64_t slice_stride, DType out_dtype, void* out, bool accumulate,
                   const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
                   bool bias_accumulate, hipStream_t stream);
 

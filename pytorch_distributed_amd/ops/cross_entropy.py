@@ -99,7 +99,17 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
             dhidden = input_grad_mm(dlogits, weight, dlogits_p).mul_(dloss.to(weight.dtype)).view(ctx.hidden_shape)
         if ctx.needs_input_grad[1]:
             target = _grad_target(weight, ctx.grad_sink)
-            if target is not None and not target[1] and target[0].is_contiguous():
+            if _native_lm_head_wgrad_ok(dlogits_p, h2, V):
+                # Native weight-gradient kernel over the padded buffer (its padding columns are zero), only
+                # the V real rows folded — written or accumulated straight into the owner's slot; dloss is
+                # applied to the small operand.
+                out, acc = target if target is not None and target[0].is_contiguous() else (None, False)
+                dw, _ = ext_wgrad(dlogits_p, h2 * dloss.to(weight.dtype), out, acc, V)
+                dweight = dw if out is None else None
+                if target is not None and out is None:
+                    target[0].add_(dweight)
+                    dweight = None
+            elif target is not None and not target[1] and target[0].is_contiguous():
                 # first writer of the owner's slot in this pass: the GEMM writes it, dloss is applied to
                 # the small operand instead of a pass over the [V, d] result
                 torch.mm(dlogits.t(), h2 * dloss.to(weight.dtype), out=target[0])
@@ -109,6 +119,20 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
                     target[0].add_(dweight)
                     dweight = None
         return dhidden, dweight, None, None
+
+
+def _native_lm_head_wgrad_ok(dlogits_p, h2, V) -> bool:
+    import os
+    if os.environ.get("PDA_NO_NATIVE_WGRAD") == "1" or dlogits_p.dtype != torch.bfloat16:
+        return False
+    M, vp = dlogits_p.shape
+    d = h2.shape[1]
+    return (dlogits_p.is_contiguous() and h2.is_contiguous() and (V * d) % 4 == 0
+            and _ext.require().wgrad_supported(M, vp, d))
+
+
+def ext_wgrad(dlogits_p, h2, out, accumulate, rows):
+    return _ext.require().linear_wgrad(dlogits_p, h2, False, out, accumulate, None, False, rows)
 
 
 def cross_entropy(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
