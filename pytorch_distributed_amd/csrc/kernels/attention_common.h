@@ -107,8 +107,20 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
   return r;
 }
 
-__device__ __forceinline__ float lane_pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float lane_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// Exchange between lane l and lane l ^ 32 with v_permlane32_swap (one VALU instruction; given the
+// same value twice it returns the lower half's values in both halves and the upper half's values in
+// both halves) instead of a ds_bpermute round trip through the LDS crossbar, which sits on the
+// critical path between the row maximum and the exponentials of every tile.
+__device__ __forceinline__ float lane_pair_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto both = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(both[0]), __uint_as_float(both[1]));
+}
+__device__ __forceinline__ float lane_pair_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto both = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(both[0]) + __uint_as_float(both[1]);
+}
 
 // ------------------------------------------------------------------ attention dropout --
 // Counter-based dropout mask shared by the forward and both backward kernels. The T x T
