@@ -425,3 +425,42 @@ def test_rocprof_trace_merge_builds_per_rank_chrome_traces(tmp_path):
     assert b["compute_us"] == 60.0 and b["non_compute_us"] == 10.0
     res = ta.analyze_dir(str(tmp_path / "traces" / "ddp"))
     assert set(res) == {0, 1}
+
+
+def test_counter_profile_report_from_synthetic_passes(tmp_path):
+    """Counter mode: per-dispatch rows of several rocprofv3 passes are averaged per kernel and turned
+    into utilisation / stall / conflict / traffic figures."""
+    import csv as _csv
+    import importlib.util
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("counter_profile", os.path.join(repo, "counter_profile.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    kern = "void pda::(anonymous namespace)::wgrad_kernel4<0>(unsigned short const*, long)"
+
+    def write(path, header, rows):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w", newline="") as f:
+            w = _csv.writer(f)
+            w.writerow(header)
+            w.writerows(rows)
+
+    sq = {"SQ_BUSY_CYCLES": 1000.0, "SQ_VALU_MFMA_BUSY_CYCLES": 2000.0, "SQ_WAVE_CYCLES": 8000.0,
+          "SQ_WAIT_INST_ANY": 2000.0, "SQ_INSTS_VALU": 300.0, "SQ_INSTS_MFMA": 100.0,
+          "SQ_LDS_BANK_CONFLICT": 5.0, "SQ_LDS_IDX_ACTIVE": 500.0}
+    write(str(tmp_path / "sq" / "x" / "1_counter_collection.csv"), ["Kernel_Name", "Counter_Name", "Counter_Value"],
+          [[kern, c, v] for c, v in sq.items()] + [[kern, c, v] for c, v in sq.items()])
+    write(str(tmp_path / "hbm_read" / "x" / "1_counter_collection.csv"), ["Kernel_Name", "Counter_Name", "Counter_Value"],
+          [[kern, "FETCH_SIZE", 2048.0]])
+    write(str(tmp_path / "trace" / "x" / "1_kernel_trace.csv"), ["Kernel_Name", "Start_Timestamp", "End_Timestamp"],
+          [[kern, 1000, 101000], [kern, 200000, 300000]])
+    rows = cp.collect(str(tmp_path), "wgrad")
+    (name, c), = rows.items()
+    assert name.startswith("wgrad_kernel4") and c["dispatches"] == 2 and abs(c["duration_us"] - 100.0) < 1e-9
+    d = cp.derive(c)
+    assert abs(d["mfma_busy"] - 0.5) < 1e-9 and abs(d["wait_share"] - 0.25) < 1e-9
+    assert abs(d["valu_per_mfma"] - 3.0) < 1e-9 and abs(d["lds_conflict"] - 0.01) < 1e-9
+    assert d["l2_hit"] is None and abs(d["hbm_read_mb"] - 2.0) < 1e-9
+    assert abs(d["hbm_read_gbps"] - 2048 * 1024 / 100e-6 / 1e9) < 1e-6
+    assert cp.collect(str(tmp_path), "attention") == {}
