@@ -449,18 +449,22 @@ def test_counter_profile_report_from_synthetic_passes(tmp_path):
     sq = {"SQ_BUSY_CYCLES": 1000.0, "SQ_VALU_MFMA_BUSY_CYCLES": 2000.0, "SQ_WAVE_CYCLES": 8000.0,
           "SQ_WAIT_INST_ANY": 2000.0, "SQ_INSTS_VALU": 300.0, "SQ_INSTS_MFMA": 100.0,
           "SQ_LDS_BANK_CONFLICT": 5.0, "SQ_LDS_IDX_ACTIVE": 500.0}
-    write(str(tmp_path / "sq" / "x" / "1_counter_collection.csv"), ["Kernel_Name", "Counter_Name", "Counter_Value"],
-          [[kern, c, v] for c, v in sq.items()] + [[kern, c, v] for c, v in sq.items()])
-    write(str(tmp_path / "hbm_read" / "x" / "1_counter_collection.csv"), ["Kernel_Name", "Counter_Name", "Counter_Value"],
-          [[kern, "FETCH_SIZE", 2048.0]])
-    write(str(tmp_path / "trace" / "x" / "1_kernel_trace.csv"), ["Kernel_Name", "Start_Timestamp", "End_Timestamp"],
-          [[kern, 1000, 101000], [kern, 200000, 300000]])
+    head = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    write(str(tmp_path / "sq" / "x" / "1_counter_collection.csv"), head,
+          [[1, kern, c, v] for c, v in sq.items()] + [[2, kern, c, v] for c, v in sq.items()])
+    write(str(tmp_path / "hbm_read" / "x" / "1_counter_collection.csv"), head, [[1, kern, "FETCH_SIZE", 2048.0]])
+    write(str(tmp_path / "trace" / "x" / "1_kernel_trace.csv"), ["Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp"],
+          [[1, kern, 1000, 101000], [2, kern, 200000, 300000]])
     rows = cp.collect(str(tmp_path), "wgrad")
     (name, c), = rows.items()
     assert name.startswith("wgrad_kernel4") and c["dispatches"] == 2 and abs(c["duration_us"] - 100.0) < 1e-9
-    d = cp.derive(c)
+    d = cp.derive(c, simd_hz=2000.0 / 100e-6 / 0.5)  # chosen so that 2000 busy cycles in 100 us are 50 %
     assert abs(d["mfma_busy"] - 0.5) < 1e-9 and abs(d["wait_share"] - 0.25) < 1e-9
     assert abs(d["valu_per_mfma"] - 3.0) < 1e-9 and abs(d["lds_conflict"] - 0.01) < 1e-9
     assert d["l2_hit"] is None and abs(d["hbm_read_mb"] - 2.0) < 1e-9
     assert abs(d["hbm_read_gbps"] - 2048 * 1024 / 100e-6 / 1e9) < 1e-6
     assert cp.collect(str(tmp_path), "attention") == {}
+    # window between the last two bursts of a marker kernel: ids (12, 112]
+    trace = [{"Dispatch_Id": str(i), "Kernel_Name": "adamw" if i in (10, 11, 12, 110, 111, 112) else "gemm"} for i in range(1, 120)]
+    assert cp.window(trace, "adamw") == (12, 112)
+    assert cp.window(trace, "") is None and cp.window(trace[:50], "adamw") is None
