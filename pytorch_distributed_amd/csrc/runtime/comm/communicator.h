@@ -6,9 +6,14 @@
 //   RcclCommunicator    GPUs. One ncclComm per process created from a unique id that rank 0
 //                       publishes in the rendezvous store; collectives run on two HIP streams
 //                       the communicator owns (queue kGather for all-gathers / broadcasts,
-//                       queue kReduce for all-reduces / reduce-scatters) so a parameter
-//                       prefetch never queues behind a gradient reduction; hipEvent fences
-//                       order them against the caller's stream in both directions; a
+//                       queue kReduce for all-reduces / reduce-scatters), never on the compute
+//                       stream. RCCL executes the collectives of ONE communicator in the order
+//                       they were issued whatever stream they are on, so the two queues do not
+//                       make a gather overtake an earlier reduction; what they separate is the
+//                       bookkeeping (fences, waits, trace rows) of the two traffic classes, and
+//                       they are the seam where a second library communicator would go if
+//                       gathers and reductions are ever to run concurrently. hipEvent fences
+//                       order the queues against the caller's stream in both directions; a
 //                       watchdog aborts the communicator (ncclCommAbort) when a collective
 //                       exceeds the timeout.
 //   SocketCommunicator  CPU tensors over a TCP mesh between the ranks: the device-free

@@ -25,8 +25,10 @@
 //   * one end-of-backward callback waits for all outstanding reductions and publishes the
 //     reduced shard as `.grad` of each unit's flat shard parameter.
 //
-// All-gathers run on the communicator's gather queue, reductions on its reduce queue, so a
-// prefetch never waits behind a gradient reduction.
+// All-gathers run on the communicator's gather queue, reductions on its reduce queue; neither
+// ever sits on the compute stream. (The collective library runs one communicator's collectives in
+// issue order; per unit that is a reduce-scatter plus the next all-gather under a whole block's
+// backward, see communicator.h.)
 //
 // Safety rule for every buffer: storage is only released after the collective that reads
 // or writes it has been waited on from the stream that will reuse the memory.
