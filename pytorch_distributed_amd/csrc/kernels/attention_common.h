@@ -227,6 +227,23 @@ struct TileStager {
 
   __device__ __forceinline__ void load(const bf16_raw* base, int64_t row_stride, int row0, int last_row,
                                        int tid) {
+    if (row0 + kRows - 1 <= last_row) {
+      // Whole tile in range (every tile but possibly the last): address = wave-uniform tile base +
+      // a per-lane byte offset that does not depend on the tile, so the loop carries no 64-bit
+      // address arithmetic on the vector unit (the clamped form below costs ~8 vector
+      // instructions per load, a sixth of the forward kernel's instruction count per tile).
+      const char* tile_base = reinterpret_cast<const char*>(base) + int64_t(row0) * row_stride * 2;
+      const unsigned pitch = unsigned(row_stride) * 2u;
+#pragma unroll
+      for (int i = 0; i < kPerThread; ++i) {
+        const int c = tid + i * kThreads;
+        if (kChunks % kThreads == 0 || c < kChunks) {
+          const unsigned off = unsigned(c / kChunksPerRow) * pitch + unsigned(c % kChunksPerRow) * 16u;
+          regs[i] = *reinterpret_cast<const u32x4*>(tile_base + off);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < kPerThread; ++i) {
       const int c = tid + i * kThreads;

@@ -44,7 +44,7 @@ constexpr int kBN = 64;   // keys per tile
 // them in AGPRs and copies every score across for the softmax) and lets three workgroups
 // share a CU.
 template <int D, bool kDrop>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 ? 3 : 2))) void attn_fwd_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 64 && !kDrop ? 3 : 2))) void attn_fwd_kernel(
     const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out, float* __restrict__ lse_out, int B, int T, int H,
     float scale, DropoutParams drop) {
   constexpr int kKSteps = D / 16;   // k-steps of the S^T product
@@ -127,23 +127,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
           s_acc[kb] = mfma32(kf, qf[ks], s_acc[kb]);
         }
       }
-      // ---- scale, causal mask (only on tiles that straddle the diagonal), row maximum --------
-      // The scores are first multiplied by scale * log2(e): exp2 then needs only a subtraction,
-      // and the maximum runs over VALU results: max3() is inline assembly, for which the compiler
-      // inserts no wait states after an MFMA that wrote its operands (fmaxf() on the raw MFMA
-      // results instead costs an extra canonicalising instruction per value).
+      // ---- causal mask (only on tiles that straddle the diagonal), row maximum, exponentials ------
+      // The softmax works in exp2 units: p = exp2(c * s - m) with c = scale * log2(e) and m the
+      // running maximum of c * s. The maximum is taken over the RAW scores (c > 0) and the scale is
+      // folded into one packed fused multiply-add per pair in front of the exponential, so a score
+      // costs max3 (1/2), fma (1/2), exp2 (1), sum (1/2), convert (1/2) instructions.
+      // max3() is inline assembly and the compiler inserts no MFMA -> VALU wait states for inline
+      // assembly, so the wait is explicit: 24 idle cycles cover the 8-pass MFMA that wrote last
+      // (the fence also ties the accumulators to this point of the instruction stream).
       // Masked and unmasked tiles are separate code paths: folded into one, the per-element
       // compare / select of the mask is evaluated on every tile.
       const int key0 = j * kBN;
-      const f32x2 c2 = {c, c};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const f32x2 t = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} * c2;
-          s_acc[kb][i] = t[0];
-          s_acc[kb][i + 1] = t[1];
-        }
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s_acc[0]), "+v"(s_acc[1]));
       auto masked_row_max = [&](auto masked) {
         float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
@@ -163,18 +158,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       float mx;
       if (__builtin_expect(key0 + kBN - 1 > q0, 0)) mx = masked_row_max(std::true_type{});  // wave-uniform
       else mx = masked_row_max(std::false_type{});
-      mx = lane_pair_max(mx);
+      mx = c * lane_pair_max(mx);
       const float m_new = fmaxf(m_run, mx);  // finite: key 0 is visible to every query
       const bool grew = m_new > m_run;
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
-      const f32x2 m2 = {m_new, m_new};
+      const f32x2 c2 = {c, c}, neg_m2 = {-m_new, -m_new};
       f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-          const f32x2 e = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} - m2;
+          const f32x2 e = __builtin_elementwise_fma(f32x2{s_acc[kb][i], s_acc[kb][i + 1]}, c2, neg_m2);
           const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
           s_acc[kb][i] = p[0];
           s_acc[kb][i + 1] = p[1];
