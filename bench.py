@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None,
                     help="transformer blocks per sharding unit (default: measured at start-up)")
+    ap.add_argument("--fsdp-resident-gb", default="0",
+                    help="FULL_SHARD: GiB of unsharded parameters kept from forward to backward ('auto' = a tenth of "
+                         "free memory); 0 = every unit is all-gathered again in backward")
     ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
     ap.add_argument("--comm", choices=["auto", "native", "c10d"], default="auto",
                     help="native = the framework's RCCL communicator; c10d = a torch.distributed group behind the same "
@@ -214,10 +217,12 @@ def main():
                 blocks = model.transformer.h if hasattr(model, "transformer") else model.model.layers
                 block_bytes = sum(p.numel() * p.element_size() for p in blocks[0].parameters())
                 unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
+            resident = "auto" if args.fsdp_resident_gb == "auto" else float(args.fsdp_resident_gb)
             model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], unit_blocks=unit_blocks,
-                                  force_collectives=args.wrap_single, reduce_fp32=args.reduce_fp32)
+                                  force_collectives=args.wrap_single, reduce_fp32=args.reduce_fp32,
+                                  resident_gb=resident)
             parallelism = f"fsdp_{args.strategy.lower()}{world}"
-            detail = {"unit_blocks": unit_blocks}
+            detail = {"unit_blocks": unit_blocks, "resident_gb": resident}
         else:
             parallelism = "single"
         optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1, capturable=args.hip_graph)

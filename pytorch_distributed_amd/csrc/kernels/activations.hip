@@ -1,9 +1,13 @@
 // GELU (tanh approximation, "gelu_new") and SwiGLU forward / backward for gfx950.
 //
-// Pure streaming kernels: 16-byte vector accesses, fp32 math in registers,
-// grid capped at 8 workgroups per CU with a grid-stride loop. The backward
-// kernels recompute the activation from the saved pre-activation, so the
-// forward never has to keep tanh / sigmoid values.
+// Pure streaming kernels: 16-byte vector accesses, fp32 math in registers. The GELU kernels
+// launch ONE 16-byte vector per thread (a grid of tens of thousands of workgroups) and mark
+// their loads and stores non-temporal: on MI355X that streams at 6.1-6.5 TB/s where a grid capped
+// at 8 workgroups per CU with a grid-stride loop reaches 5.0-5.3 TB/s (backward 201 -> 155 us,
+// forward 126 -> 107 us on a [32768, 5120] bf16 activation; tools/micro/stream_probe.hip —
+// more vectors in flight per thread, contiguous chunks per workgroup and packed fp32 math all
+// measured slower or equal). The backward kernels recompute the activation from the saved
+// pre-activation, so the forward never has to keep tanh / sigmoid values.
 //
 // The activation math lives in gelu_math.h (shared with the GEMM epilogues of gemm_fused.hip).
 #include "common.h"
@@ -14,9 +18,9 @@ namespace pda {
 namespace {
 
 constexpr int kThreads = 256;
-inline unsigned stream_grid(int64_t nvec) {
-  int64_t blocks = ceil_div(nvec, kThreads);
-  if (blocks > 2048) blocks = 2048;
+// one vector per thread
+inline unsigned flat_grid(int64_t nvec) {
+  const int64_t blocks = ceil_div(nvec, kThreads);
   return (unsigned)(blocks < 1 ? 1 : blocks);
 }
 
@@ -24,17 +28,15 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void gelu_fwd_kernel(const T* __restrict__ u, T* __restrict__ y,
                                                             int64_t n) {
   constexpr int kVec = VecIO<T>::kVec;
-  const int64_t stride = int64_t(gridDim.x) * kThreads * kVec;
-  for (int64_t i = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * kVec; i < n; i += stride) {
-    if (i + kVec <= n) {
-      float a[kVec], o[kVec];
-      VecIO<T>::load(u + i, a);
+  const int64_t i = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * kVec;
+  if (i + kVec <= n) {
+    float a[kVec], o[kVec];
+    VecIO<T>::unpack(VecIO<T>::load_raw_nt(u + i), a);
 #pragma unroll
-      for (int k = 0; k < kVec; ++k) o[k] = gelu_f(a[k]);
-      VecIO<T>::store(y + i, o);
-    } else {
-      for (int64_t j = i; j < n; ++j) VecIO<T>::store1(y + j, gelu_f(VecIO<T>::load1(u + j)));
-    }
+    for (int k = 0; k < kVec; ++k) o[k] = gelu_f(a[k]);
+    VecIO<T>::store_raw_nt(y + i, VecIO<T>::pack(o));
+  } else {
+    for (int64_t j = i; j < n; ++j) VecIO<T>::store1(y + j, gelu_f(VecIO<T>::load1(u + j)));
   }
 }
 
@@ -43,19 +45,18 @@ __global__ __launch_bounds__(kThreads) void gelu_bwd_kernel(const T* __restrict_
                                                             const T* __restrict__ u,
                                                             T* __restrict__ du, int64_t n) {
   constexpr int kVec = VecIO<T>::kVec;
-  const int64_t stride = int64_t(gridDim.x) * kThreads * kVec;
-  for (int64_t i = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * kVec; i < n; i += stride) {
-    if (i + kVec <= n) {
-      float a[kVec], g[kVec], o[kVec];
-      VecIO<T>::load(u + i, a);
-      VecIO<T>::load(dy + i, g);
+  const int64_t i = (int64_t(blockIdx.x) * kThreads + threadIdx.x) * kVec;
+  if (i + kVec <= n) {
+    float a[kVec], g[kVec], o[kVec];
+    const typename VecIO<T>::Raw ur = VecIO<T>::load_raw_nt(u + i), gr = VecIO<T>::load_raw_nt(dy + i);
+    VecIO<T>::unpack(ur, a);
+    VecIO<T>::unpack(gr, g);
 #pragma unroll
-      for (int k = 0; k < kVec; ++k) o[k] = g[k] * gelu_grad_f(a[k]);
-      VecIO<T>::store(du + i, o);
-    } else {
-      for (int64_t j = i; j < n; ++j)
-        VecIO<T>::store1(du + j, VecIO<T>::load1(dy + j) * gelu_grad_f(VecIO<T>::load1(u + j)));
-    }
+    for (int k = 0; k < kVec; ++k) o[k] = g[k] * gelu_grad_f(a[k]);
+    VecIO<T>::store_raw_nt(du + i, VecIO<T>::pack(o));
+  } else {
+    for (int64_t j = i; j < n; ++j)
+      VecIO<T>::store1(du + j, VecIO<T>::load1(dy + j) * gelu_grad_f(VecIO<T>::load1(u + j)));
   }
 }
 
@@ -71,11 +72,12 @@ __global__ __launch_bounds__(kThreads) void swiglu_fwd_kernel(const T* __restric
     const int64_t r = v / fv;
     const int c = (int)(v - r * fv) * kVec;
     float g[kVec], up[kVec], o[kVec];
-    VecIO<T>::load(x + r * 2 * f + c, g);
-    VecIO<T>::load(x + r * 2 * f + f + c, up);
+    const typename VecIO<T>::Raw gr = VecIO<T>::load_raw_nt(x + r * 2 * f + c), ur = VecIO<T>::load_raw_nt(x + r * 2 * f + f + c);
+    VecIO<T>::unpack(gr, g);
+    VecIO<T>::unpack(ur, up);
 #pragma unroll
     for (int k = 0; k < kVec; ++k) o[k] = g[k] * sigmoid_f(g[k]) * up[k];
-    VecIO<T>::store(y + r * f + c, o);
+    VecIO<T>::store_raw_nt(y + r * f + c, VecIO<T>::pack(o));
   }
 }
 
@@ -91,9 +93,11 @@ __global__ __launch_bounds__(kThreads) void swiglu_bwd_kernel(const T* __restric
     const int64_t r = v / fv;
     const int c = (int)(v - r * fv) * kVec;
     float g[kVec], up[kVec], d[kVec], dg[kVec], dup[kVec];
-    VecIO<T>::load(x + r * 2 * f + c, g);
-    VecIO<T>::load(x + r * 2 * f + f + c, up);
-    VecIO<T>::load(dy + r * f + c, d);
+    const typename VecIO<T>::Raw gr = VecIO<T>::load_raw_nt(x + r * 2 * f + c), ur = VecIO<T>::load_raw_nt(x + r * 2 * f + f + c),
+                                 dr = VecIO<T>::load_raw_nt(dy + r * f + c);
+    VecIO<T>::unpack(gr, g);
+    VecIO<T>::unpack(ur, up);
+    VecIO<T>::unpack(dr, d);
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
       const float s = sigmoid_f(g[k]);
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(kThreads) void swiglu_bwd_kernel(const T* __restric
       dup[k] = d[k] * silu;
       dg[k] = d[k] * up[k] * (s + silu * (1.f - s));
     }
-    VecIO<T>::store(dx + r * 2 * f + c, dg);
-    VecIO<T>::store(dx + r * 2 * f + f + c, dup);
+    VecIO<T>::store_raw_nt(dx + r * 2 * f + c, VecIO<T>::pack(dg));
+    VecIO<T>::store_raw_nt(dx + r * 2 * f + f + c, VecIO<T>::pack(dup));
   }
 }
 
@@ -111,30 +115,30 @@ __global__ __launch_bounds__(kThreads) void swiglu_bwd_kernel(const T* __restric
 void gelu_forward(DType dtype, const void* u, void* y, int64_t n, hipStream_t stream) {
   if (n <= 0) return;
   if (dtype == kBF16)
-    hipLaunchKernelGGL(gelu_fwd_kernel<bf16_raw>, dim3(stream_grid(ceil_div(n, 8))), dim3(kThreads), 0,
+    hipLaunchKernelGGL(gelu_fwd_kernel<bf16_raw>, dim3(flat_grid(ceil_div(n, 8))), dim3(kThreads), 0,
                        stream, (const bf16_raw*)u, (bf16_raw*)y, n);
   else
-    hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(stream_grid(ceil_div(n, 4))), dim3(kThreads), 0,
+    hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(flat_grid(ceil_div(n, 4))), dim3(kThreads), 0,
                        stream, (const float*)u, (float*)y, n);
 }
 
 void gelu_backward(DType dtype, const void* dy, const void* u, void* du, int64_t n, hipStream_t stream) {
   if (n <= 0) return;
   if (dtype == kBF16)
-    hipLaunchKernelGGL(gelu_bwd_kernel<bf16_raw>, dim3(stream_grid(ceil_div(n, 8))), dim3(kThreads), 0,
+    hipLaunchKernelGGL(gelu_bwd_kernel<bf16_raw>, dim3(flat_grid(ceil_div(n, 8))), dim3(kThreads), 0,
                        stream, (const bf16_raw*)dy, (const bf16_raw*)u, (bf16_raw*)du, n);
   else
-    hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(stream_grid(ceil_div(n, 4))), dim3(kThreads), 0,
+    hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(flat_grid(ceil_div(n, 4))), dim3(kThreads), 0,
                        stream, (const float*)dy, (const float*)u, (float*)du, n);
 }
 
 void swiglu_forward(DType dtype, const void* x, void* y, int64_t rows, int f, hipStream_t stream) {
   if (rows <= 0) return;
   if (dtype == kBF16)
-    hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_raw>, dim3(stream_grid(rows * (f / 8))), dim3(kThreads),
+    hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_raw>, dim3(flat_grid(rows * (f / 8))), dim3(kThreads),
                        0, stream, (const bf16_raw*)x, (bf16_raw*)y, rows, f);
   else
-    hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(stream_grid(rows * (f / 4))), dim3(kThreads), 0,
+    hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(flat_grid(rows * (f / 4))), dim3(kThreads), 0,
                        stream, (const float*)x, (float*)y, rows, f);
 }
 
@@ -142,10 +146,10 @@ void swiglu_backward(DType dtype, const void* dy, const void* x, void* dx, int64
                      hipStream_t stream) {
   if (rows <= 0) return;
   if (dtype == kBF16)
-    hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_raw>, dim3(stream_grid(rows * (f / 8))), dim3(kThreads),
+    hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_raw>, dim3(flat_grid(rows * (f / 8))), dim3(kThreads),
                        0, stream, (const bf16_raw*)dy, (const bf16_raw*)x, (bf16_raw*)dx, rows, f);
   else
-    hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(stream_grid(rows * (f / 4))), dim3(kThreads), 0,
+    hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(flat_grid(rows * (f / 4))), dim3(kThreads), 0,
                        stream, (const float*)dy, (const float*)x, (float*)dx, rows, f);
 }
 

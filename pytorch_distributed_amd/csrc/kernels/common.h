@@ -56,6 +56,13 @@ struct VecIO<bf16_raw> {
   __device__ static __forceinline__ Raw load_raw(const bf16_raw* p) {
     return *reinterpret_cast<const u32x4*>(p);
   }
+  // Non-temporal forms for data a streaming kernel touches once (no reuse to keep in the caches).
+  __device__ static __forceinline__ Raw load_raw_nt(const bf16_raw* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  }
+  __device__ static __forceinline__ void store_raw_nt(bf16_raw* p, const Raw& w) {
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
+  }
   __device__ static __forceinline__ void unpack(const Raw& w, float (&out)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -85,6 +92,12 @@ struct VecIO<float> {
   typedef f32x4 Raw;
   __device__ static __forceinline__ Raw load_raw(const float* p) {
     return *reinterpret_cast<const f32x4*>(p);
+  }
+  __device__ static __forceinline__ Raw load_raw_nt(const float* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  }
+  __device__ static __forceinline__ void store_raw_nt(float* p, const Raw& w) {
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
   }
   __device__ static __forceinline__ void unpack(const Raw& w, float (&out)[4]) {
 #pragma unroll

@@ -23,7 +23,15 @@
 //     "pre-backward" moment — unit i is all-gathered again and the units backward will
 //     visit next are prefetched. No Python runs in backward;
 //   * one end-of-backward callback waits for all outstanding reductions and publishes the
-//     reduced shard as `.grad` of each unit's flat shard parameter.
+//     reduced shard as `.grad` of each unit's flat shard parameter;
+//   * resident budget (set_resident_budget): FULL_SHARD units, counted from the LAST one (the
+//     first that backward needs), keep their unsharded parameters from forward to their own
+//     backward while their bytes fit the budget. Those units are not re-gathered in backward —
+//     the all-gathers that sit exposed at the start of backward disappear — and their memory is
+//     still released unit by unit as backward passes them. With 288 GB per GPU the whole bf16
+//     model of the GPT-2 / 7B-class configurations fits a small fraction of free memory. How
+//     many unsharded units exist at any time is otherwise bounded by the prefetch depths
+//     (depth + 1 in either direction), which is the rate limit on all-gathers in flight.
 //
 // All-gathers run on the communicator's gather queue, reductions on its reduce queue; neither
 // ever sits on the compute stream. (The collective library runs one communicator's collectives in
@@ -486,8 +494,31 @@ class ShardedRuntime {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     ShardedUnit& u = *units_[index];
     // A recomputed forward inside backward must not reshard: the backward still needs the parameters.
-    if (u.strategy_ == kFullShard && u.reshard_after_forward && !in_backward()) u.reshard();
+    const bool resident = index < (int64_t)resident_.size() && resident_[index];
+    if (u.strategy_ == kFullShard && u.reshard_after_forward && !resident && !in_backward()) u.reshard();
   }
+
+  // Chooses the units that stay unsharded between forward and backward: the longest suffix of
+  // FULL_SHARD units (the root excluded: it never reshards inside a pass) whose unsharded
+  // parameters fit `bytes`. Must be called with the same value on every rank (the choice
+  // changes which all-gathers are issued). Returns the number of resident units.
+  int64_t set_resident_budget(int64_t bytes) {
+    std::lock_guard<std::recursive_mutex> lock(mu_);
+    resident_.assign(units_.size(), false);
+    resident_bytes_ = 0;
+    int64_t count = 0;
+    for (int64_t i = (int64_t)units_.size() - 1; i >= 1; --i) {
+      ShardedUnit& u = *units_[i];
+      if (u.strategy_ != kFullShard || !u.reshard_after_forward) continue;
+      const int64_t unit_bytes = u.padded_numel_ * (int64_t)u.full_param_.element_size();
+      if (resident_bytes_ + unit_bytes > bytes) break;
+      resident_[i] = true;
+      resident_bytes_ += unit_bytes;
+      ++count;
+    }
+    return count;
+  }
+  int64_t resident_bytes() const { return resident_bytes_; }
 
   void pre_backward(int64_t index) {
     std::lock_guard<std::recursive_mutex> lock(mu_);
@@ -548,6 +579,8 @@ class ShardedRuntime {
   bool require_sync_ = true;
   bool pre_backward_seen_ = false;
   int64_t num_abandoned_passes_ = 0;
+  std::vector<bool> resident_;  // units that keep their unsharded parameters from forward to backward
+  int64_t resident_bytes_ = 0;
   std::shared_ptr<bool> alive_;
 };
 
@@ -642,5 +675,7 @@ void bind_fsdp(py::module_& m) {
       .def("pre_forward", &ShardedRuntime::pre_forward, py::arg("index"), py::call_guard<py::gil_scoped_release>())
       .def("post_forward", &ShardedRuntime::post_forward, py::arg("index"), py::arg("outputs"))
       .def("pre_backward", &ShardedRuntime::pre_backward, py::arg("index"), py::call_guard<py::gil_scoped_release>())
+      .def("set_resident_budget", &ShardedRuntime::set_resident_budget, py::arg("bytes"))
+      .def_property_readonly("resident_bytes", &ShardedRuntime::resident_bytes)
       .def_property_readonly("num_abandoned_passes", &ShardedRuntime::num_abandoned_passes);
 }

@@ -58,10 +58,18 @@ class FSDP(nn.Module):
 
     def __init__(self, module: nn.Module, sharding_strategy=ShardingStrategy.FULL_SHARD,
                  process_group=None, forward_prefetch: int = 1, backward_prefetch: int = 1,
-                 force_collectives: bool = False, reduce_fp32: bool = False, communicator=None):
+                 force_collectives: bool = False, reduce_fp32: bool = False, communicator=None,
+                 resident_gb=0.0):
         """``reduce_fp32``: reduce bf16 gradients through an fp32 copy (twice the bytes on the wire,
         no rounding between the ranks' contributions); the default reduces in the gradient dtype.
-        ``process_group``: a torch.distributed group to run on instead of the native communicator."""
+        ``process_group``: a torch.distributed group to run on instead of the native communicator.
+        ``resident_gb`` (read from the root instance; FULL_SHARD only): GiB of unsharded parameters
+        that may stay allocated between forward and backward. The last units of the model — the
+        first ones backward visits — keep their parameters while they fit and are then not
+        all-gathered again in backward; 0 is textbook FULL_SHARD, a budget covering the model gives
+        SHARD_GRAD_OP's traffic with FULL_SHARD's unit-by-unit release in backward. ``"auto"``
+        takes a tenth of the device memory that is free at the first forward (the minimum over the
+        ranks, so that every rank issues the same collectives)."""
         super().__init__()
         self.module = module
         self.sharding_strategy = _as_strategy(sharding_strategy)
@@ -70,6 +78,8 @@ class FSDP(nn.Module):
         self.rank = self.communicator.rank
         self.forward_prefetch = forward_prefetch
         self.backward_prefetch = backward_prefetch
+        self.resident_gb = resident_gb
+        self.resident_units = 0
         first = next((p for p in module.parameters() if p.requires_grad), None)
         if first is not None and first.is_cuda != self.communicator.on_gpu:
             raise RuntimeError(f"FSDP: the '{self.communicator.backend}' communicator cannot move "
@@ -136,6 +146,21 @@ class FSDP(nn.Module):
         self._order = units
         self._runtime = _ext.require().ShardedRuntime([u.unit for u in units], self.forward_prefetch,
                                                       self.backward_prefetch)
+        budget = self._resident_budget_bytes()
+        if budget > 0:
+            self.resident_units = self._runtime.set_resident_budget(budget)
+
+    def _resident_budget_bytes(self) -> int:
+        if self.sharding_strategy is not ShardingStrategy.FULL_SHARD:
+            return 0
+        if self.resident_gb != "auto":
+            return int(float(self.resident_gb or 0.0) * 2**30)
+        dev = self.flat_param.device
+        free = torch.cuda.mem_get_info(dev)[0] if dev.type == "cuda" else 0
+        budget = torch.tensor([-0.10 * free], dtype=torch.float64, device=dev)
+        if self.world_size > 1:  # the smallest budget of any rank, agreed before the first collective of the pass
+            comm.all_reduce(budget, "max", self.communicator)
+        return int(-budget.item())
 
     # ------------------------------------------------------------------ hooks
     def _units(self) -> List["FSDP"]:

@@ -142,6 +142,36 @@ def test_fsdp_full_shard_collective_sequence_single_process():
         comm.shutdown()
 
 
+def test_fsdp_resident_budget_skips_the_backward_all_gathers_of_the_last_units():
+    """A budget that fits two blocks: b3 and b2 keep their parameters from forward to backward and are
+    not gathered again; b1 still is. Gradients equal the plain FULL_SHARD run's."""
+    from pytorch_distributed_amd.parallel import ShardingStrategy, comm, fsdp_wrap_gpt
+
+    rec = _recording()
+    try:
+        ref = fsdp_wrap_gpt(_three_blocks(), ShardingStrategy.FULL_SHARD, force_collectives=True)
+        block_bytes = [m.unit for m in ref.modules() if type(m).__name__ == "FSDP"][1].padded_numel * 4
+        model = fsdp_wrap_gpt(_three_blocks(), ShardingStrategy.FULL_SHARD, force_collectives=True,
+                              resident_gb=2.5 * block_bytes / 2**30)
+        x, y = _batch(1, 2)
+        ref(x, y).backward()
+        rec.log(clear=True)
+        model(x, y).backward()
+        assert model.resident_units == 2
+        log = rec.log(clear=True)
+        kinds = [k for k, _, _ in log]
+        assert kinds.count("all_gather") == 5 and kinds.count("reduce_scatter") == 4, kinds
+        for a, b in zip(model.parameters(), ref.parameters()):
+            torch.testing.assert_close(a.grad, b.grad)
+        units = [m.unit for m in model.modules() if type(m).__name__ == "FSDP"]
+        assert not any(u.is_unsharded() for u in units)  # everything is released by the end of backward
+        # the second pass behaves the same (the kept units were resharded after their backward)
+        model(x, y).backward()
+        assert [k for k, _, _ in rec.log(clear=True)].count("all_gather") == 5
+    finally:
+        comm.shutdown()
+
+
 def test_shard_grad_op_and_no_shard_sequences_single_process():
     from pytorch_distributed_amd.parallel import ShardingStrategy, comm, fsdp_wrap_gpt
 

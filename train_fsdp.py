@@ -21,11 +21,11 @@ from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
 def setup_fsdp_model(model, device, sharding_strategy_name="FULL_SHARD", unit_blocks=1, reduce_fp32=False,
-                     force_collectives=False):
+                     force_collectives=False, resident_gb=0.0):
     """Per-block wrapping plus the root unit (the reference's layout when ``unit_blocks == 1``)."""
     model = model.to(device)
     strategy = ShardingStrategy[sharding_strategy_name]
-    kw = dict(reduce_fp32=reduce_fp32, force_collectives=force_collectives)
+    kw = dict(reduce_fp32=reduce_fp32, force_collectives=force_collectives, resident_gb=resident_gb)
     if unit_blocks == 1:
         for i, block in enumerate(model.transformer.h):
             model.transformer.h[i] = FSDP(block, sharding_strategy=strategy, **kw)
@@ -39,6 +39,9 @@ def main():
                     choices=["FULL_SHARD", "SHARD_GRAD_OP", "NO_SHARD"], help="FSDP sharding strategy")
     ap.add_argument("--fsdp-unit-blocks", type=int, default=None,
                     help="transformer blocks per sharding unit (default: from the start-up measurement)")
+    ap.add_argument("--fsdp-resident-gb", default="0",
+                    help="FULL_SHARD: GiB of unsharded parameters that may stay allocated from forward to backward "
+                         "(the last units keep theirs and are not all-gathered again); 'auto' = a tenth of free memory")
     ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
     ap.add_argument("--force-collectives", action="store_true",
                     help="issue the collectives even at world size 1 (single-GPU rehearsal of the communication path)")
@@ -62,7 +65,9 @@ def main():
         blocks = model.transformer.h
         block_bytes = sum(p.numel() * p.element_size() for p in blocks[0].parameters())
         unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
-    model = setup_fsdp_model(model, device, args.strategy, unit_blocks, args.reduce_fp32, args.force_collectives)
+    resident = "auto" if args.fsdp_resident_gb == "auto" else float(args.fsdp_resident_gb)
+    model = setup_fsdp_model(model, device, args.strategy, unit_blocks, args.reduce_fp32, args.force_collectives,
+                             resident_gb=resident)
     if rank == 0:
         print(f"Model wrapped with FSDP ({args.strategy}, {unit_blocks} block(s) per unit)")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
