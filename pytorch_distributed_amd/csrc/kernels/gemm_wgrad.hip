@@ -548,6 +548,260 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
   }
 }
 
+// ---- four-wave variant on 16 x 16 x 32 MFMAs ----------------------------------------------------
+// Same 256 x 256 tile over 2 x 2 waves of 128 x 128, same LDS-DMA ring, but the products are
+// v_mfma_f32_16x16x32_bf16: 64 accumulator tiles of 16 x 16 per wave (still 256 accumulator
+// registers) and ONE MFMA k-step (32 rows of M) per pipeline stage. Why: the 32 x 32 x 16 kernel above
+// runs power-throttled (effective clock 2.00 GHz in the GPT-2 large step, against 2.13-2.20 GHz for
+// the library's 16 x 16 kernels next to it), and at equal cycles per FLOP the chip holds a higher
+// clock on the 16 x 16 x 32 shape. Measured: 1-2 % faster than the 32 x 32 x 16 kernel back to back in
+// isolation (c_fc 404 vs 411 us incl. the slice reduction), 1 % slower inside the training step
+// (306.6 vs 303.0 us average): per stage the 16 x 16 form leaves the instruction issue port 8 of every
+// 16 cycles instead of 24 of every 32, and the 32 fragment reads plus 8 LDS-DMA loads (tens of issue
+// cycles each) no longer fit the MFMAs' shadow. Both kernels sit near 1,900 cycles per stage against
+// 1,024 of matrix work: the operand feed (3.4 GB through L2 -> LDS per c_fc gradient), not the
+// matrix pipe or its clock, sets the pace. Opt-in (PDA_WGRAD_MFMA=16).
+//   * k order: lane group g (lane / 16) of an MFMA operand holds contraction slots 8g..8g+7; they are
+//     fed tile rows {4g..4g+3, 16+4g..16+4g+3} — any assignment works as long as both operands use the
+//     same one — so that the first transposed read of every fragment touches rows 0-15 and the second
+//     rows 16-31, and the two groups of a half-wave read rows that differ in bit 2;
+//   * swizzle: 16-byte chunk index XOR ((row & 3) << 2 | ((row >> 2) & 1) << 1): the 32 lanes of a
+//     half-wave (rows 4g + q for two values of g, four 8-byte pieces per row) then cover all 64 banks
+//     once. Rows that differ by a multiple of 8 share the swizzle, so one per-lane source pointer per
+//     operand still serves every LDS-DMA load of a wave;
+//   * schedule: all 32 fragment reads of stage t+1 are issued under the first 32 MFMAs of stage t
+//     into the other half of a double-buffered fragment file, the 8 LDS-DMA loads of stage t+4 under
+//     the last 32 into the slot of stage t itself (its fragments are in registers by then): four
+//     stages, three of them (96 KiB per CU) in flight behind the one being read, one barrier and one
+//     counted wait (vmcnt(16)) per stage;
+//   * the product is formed with the B-operand fragment on the MFMA's row side, so a lane ends up
+//     with four CONSECUTIVE output columns per accumulator tile: the fp32 partial tile leaves in
+//     16-byte stores.
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).
+// The 64-MFMA stage body below must be straight-line code with constant register indices whatever the
+// loop unroller's size limits say.
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ int wg_tile_off16(int row, int chunk) {
+  return row * kRowBytes + ((chunk ^ (((row & 3) << 2) | (((row >> 2) & 1) << 1))) << 4);
+}
+
+// Per-lane LDS byte offset (inside one operand tile) of the fragment of 16-column block `cblock`:
+// lane (g, i) receives tile[4g + j][16*cblock + i], j = 0..3, from the transposed read at this
+// offset and tile[16 + 4g + j][...] from the one at + 8192.
+__device__ __forceinline__ unsigned frag_base16(int cblock, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int q = i >> 2, p = i & 3;
+  const int col = cblock * 16 + 4 * p;
+  return (unsigned)(wg_tile_off16(4 * g + q, col >> 3) + (col & 7) * 2);
+}
+
+__device__ __forceinline__ const bf16_raw* stage_src16(const bf16_raw* base, int64_t ld, int row0, int col0, int cols,
+                                                       int wave, int lane) {
+  const int row = 2 * wave + (lane >> 5);  // + 8 q + 16 half for the other pieces: same swizzle
+  const int chunk = (lane & 31) ^ (((row & 3) << 2) | (((row >> 2) & 1) << 1));
+  const int col = min(col0 + chunk * 8, cols - 8);
+  return base + int64_t(row0 + row) * ld + col;
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int kUnused>
+__global__ __launch_bounds__(kThreads4) void wgrad_kernel16(const bf16_raw* __restrict__ A, int64_t lda,
+                                                            const bf16_raw* __restrict__ B, int64_t ldb,
+                                                            float* __restrict__ c_partial,
+                                                            float* __restrict__ bias_partial, int M, int I,
+                                                            int J, int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;  // 2 x 2 waves: 128 (i) x 128 (j) per wave
+
+  const int tiles_j = (J + kTile - 1) / kTile, tiles_i = (I + kTile - 1) / kTile;
+  const int n_tiles = tiles_i * tiles_j;
+  const int n_tasks = n_tiles * S;
+  const int q8 = n_tasks / 8, r8 = n_tasks % 8;
+  const int xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+  const int task = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+  const int slice = task / n_tiles;
+  const int tile = task % n_tiles;
+  const int ti = tile / tiles_j, tj = tile % tiles_j;
+
+  const int steps_total = M / kBM;
+  const int step_lo = int(int64_t(steps_total) * slice / S);
+  const int step_hi = int(int64_t(steps_total) * (slice + 1) / S);
+  const int n_steps = step_hi - step_lo;
+  if (n_steps <= 0) return;  // never true (S <= steps); removes the path that merges zero accumulators with the loop's
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[a][b][e] = 0.f;
+  const bool do_bias = bias_partial != nullptr && tj == 0;  // workgroup-uniform
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  // Fragment offsets are the same for both operands up to a wave-uniform 256 bytes per 128 columns,
+  // which goes into the (scalar) tile base: one set of eight per-lane offsets serves A and B.
+  const unsigned smem_base = lds_addr(smem);
+  unsigned f_base[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) f_base[x] = frag_base16(x, lane);
+  const unsigned a_wave = smem_base + 256u * wi, b_wave = smem_base + kTileBytes + 256u * wj;
+  const unsigned bias_off = (unsigned)wg_tile_off16(tid >> 5, tid & 31);  // rows 0..7; + 8 rows: + 4096 bytes
+
+  const bf16_raw* a_src = stage_src16(A, lda, step_lo * kBM, ti * kTile, I, wave, lane);
+  const bf16_raw* b_src = stage_src16(B, ldb, step_lo * kBM, tj * kTile, J, wave, lane);
+  // Load `i` (0..7) of stage t into ring slot `slot_idx`: pieces (half, q) of A (i < 4) or B; a piece is rows
+  // 16 half + 8 q + 2 wave, + 1 (1 KiB per wave instruction). Past the end of the slice the last stage
+  // is fetched again into a slot nobody reads, so every stage issues exactly 8 loads per wave and the
+  // counted wait is the same in every iteration.
+  auto issue_one = [&](int t, int slot_idx, int i) {
+    char* slot = smem + slot_idx * kStageBytes;
+    const int is_b = i >> 2, half = (i >> 1) & 1, q = i & 1;
+    const int64_t rows = int64_t(t < n_steps ? t : n_steps - 1) * kBM + 16 * half + 8 * q;  // wave-uniform
+    if (is_b) stage_half(b_src + rows * ldb, slot + kTileBytes, half, wave + 4 * q);
+    else stage_half(a_src + rows * lda, slot, half, wave + 4 * q);
+  };
+#pragma unroll
+  for (int t = 0; t < kStages; ++t)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_one(t, t, i);
+
+  // Fragment file (lo = contraction slots from tile rows 0-15, hi = rows 16-31). The MFMAs of a stage
+  // run row by row over the A fragments (a = 0..7, all eight B fragments each), so the B fragments and
+  // the last two A fragments are double buffered by stage parity, while A fragments 0-5 are single
+  // buffered: fragment a of the NEXT stage is requested as soon as row a of this stage has been issued.
+  s16x4 alo[2][8], ahi[2][8], blo[2][8], bhi[2][8];
+  auto read_a = [&](int set, int slot_idx, int x, int hi) {
+    const unsigned base = a_wave + slot_idx * kStageBytes + f_base[x];
+    const int as = x >= 6 ? set : 0;
+    if (hi) ahi[as][x] = tr_read<8192>(base);
+    else alo[as][x] = tr_read<0>(base);
+  };
+  auto read_b = [&](int set, int slot_idx, int x, int hi) {
+    const unsigned base = b_wave + slot_idx * kStageBytes + f_base[x];
+    if (hi) bhi[set][x] = tr_read<8192>(base);
+    else blo[set][x] = tr_read<0>(base);
+  };
+  u32x4 bias_rows[4];
+  auto bias_read = [&](int slot_idx, int j) {
+    const unsigned a_tile = smem_base + slot_idx * kStageBytes;
+    if (j == 0) bias_rows[0] = b128_read<0>(a_tile + bias_off);
+    if (j == 1) bias_rows[1] = b128_read<4096>(a_tile + bias_off);
+    if (j == 2) bias_rows[2] = b128_read<8192>(a_tile + bias_off);
+    if (j == 3) bias_rows[3] = b128_read<12288>(a_tile + bias_off);
+  };
+  {
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // stage 0: this wave's part, then everyone's
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      read_b(0, 0, x, 0);
+      read_b(0, 0, x, 1);
+      read_a(0, 0, x, 0);
+      read_a(0, 0, x, 1);
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bias_read(0, j);
+    }
+  }
+
+  auto main_loop = [&](auto with_bias) {
+    constexpr bool kBias = decltype(with_bias)::value;
+    for (int t0 = 0; t0 < n_steps; t0 += kStages) {
+      static_for<kStages>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const int t = t0 + u;
+        if (t >= n_steps) return;  // workgroup-uniform
+        constexpr int set = u & 1, nslot = (u + 1) % kStages;
+        // Stage t+1 landed (stages t+2 and t+3 stay in flight) and this wave's fragments of stage t, read
+        // during stage t-1, are in registers; after the barrier that holds for every wave, so the slot
+        // of stage t may be refilled and the slot of stage t+1 may be read.
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kBias) {  // column sums of the A tile of THIS stage (rows read during the previous one)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              bsum[2 * w] += bf16_lo(bias_rows[j][w]);
+              bsum[2 * w + 1] += bf16_hi(bias_rows[j][w]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        static_for<64>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int a = i >> 3, b = i & 7;
+          constexpr int as = a >= 6 ? set : 0;
+          acc[a][b] = mfma16(join(blo[set][b], bhi[set][b]), join(alo[as][a], ahi[as][a]), acc[a][b]);
+          // In the MFMA's shadow: next stage's B fragments and A fragments 6, 7 (other buffer) first, then A
+          // fragment x once row x is behind us, and the eight loads that refill this stage's slot.
+          if constexpr (i < 16) read_b(set ^ 1, nslot, i >> 1, i & 1);
+          else if constexpr (i < 20) read_a(set ^ 1, nslot, 6 + ((i - 16) >> 1), i & 1);
+          else if constexpr (i < 24) read_a(0, nslot, (i - 20) >> 1, i & 1);                    // A0, A1 (rows 0, 1 done at i = 15)
+          else if constexpr (i < 56 && (i & 7) < 2) read_a(0, nslot, (i >> 3) - 1, i & 1);     // A2 at 24, A3 at 32, A4 at 40, A5 at 48
+          else if constexpr (i >= 26 && (i & 3) == 2 && i < 58) issue_one(t + kStages, u, (i - 26) >> 2);
+          if constexpr (kBias && (i == 28 || i == 36)) bias_read(nslot, (i - 28) >> 3);
+          if constexpr (kBias && (i == 59 || i == 61)) bias_read(nslot, 2 + ((i - 59) >> 1));
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    }
+  };
+  if (do_bias) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the tail's dummy loads and reads
+  __syncthreads();  // the ring is reused below
+
+  // acc[a][b] register e of lane (g, c): row i = 16*(8*wi + a) + c, column j = 16*(8*wj + b) + 4*g + e.
+  // One accumulator tile at a time leaves the accumulator file (see the kernel above).
+  const int g = lane >> 4, c = lane & 15;
+  float* cp = c_partial + (int64_t(slice) * I + int64_t(ti) * kTile) * J + int64_t(tj) * kTile;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      f32x4 v = acc[a][b];
+      asm volatile("" : "+v"(v));
+      const int i = 16 * (8 * wi + a) + c;
+      const int j = 16 * (8 * wj + b) + 4 * g;
+      if (ti * kTile + i < I && tj * kTile + j < J) *reinterpret_cast<f32x4*>(cp + int64_t(i) * J + j) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  if (do_bias) {  // fold the 8 threads that share a chunk (same tid & 31) through LDS
+    float* red = reinterpret_cast<float*>(smem);  // [8][256]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 5) * kTile + (tid & 31) * 8 + e] = bsum[e];
+    __syncthreads();
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int gi = 0; gi < 8; ++gi) s += red[gi * kTile + tid];
+      if (ti * kTile + tid < I) bias_partial[int64_t(slice) * I + ti * kTile + tid] = s;
+    }
+  }
+}
+
 // out[n] (+)= sum_s partial[s][n], n over `numel` elements, 4 per thread. The last
 // `bias_blocks` workgroups of the grid do the same for the (much smaller) bias partials, so a
 // linear layer's weight and bias gradients are folded by one launch (each written or added
@@ -616,9 +870,12 @@ bool wgrad_supported(int M, int I, int J) {
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream) {
   const int n_tasks = ((I + kTile - 1) / kTile) * ((J + kTile - 1) / kTile) * S;
-  static int mode = -1, waves = 4;
+  static int mode = -1, waves = 4, mfma = 32;
   if (mode < 0) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    const char* mf = getenv("PDA_WGRAD_MFMA");  // 16 selects the 16 x 16 x 32 four-wave kernel (A/B measurements)
+    mfma = mf ? atoi(mf) : 32;
     const char* w = getenv("PDA_WGRAD_WAVES");  // 8 selects the eight-wave kernel (A/B measurements)
     waves = w ? atoi(w) : 4;
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
@@ -626,6 +883,11 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     const char* e = getenv("PDA_WGRAD_MODE");
     mode = e ? atoi(e) : 0;
+  }
+  if (waves == 4 && mode == 0 && mfma == 16) {
+    hipLaunchKernelGGL(wgrad_kernel16<0>, dim3((unsigned)n_tasks), dim3(kThreads4), kStages * kStageBytes, stream,
+                       (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
+    return;
   }
   if (waves == 4 && mode == 0) {
     hipLaunchKernelGGL(wgrad_kernel4<0>, dim3((unsigned)n_tasks), dim3(kThreads4), kStages * kStageBytes, stream,
