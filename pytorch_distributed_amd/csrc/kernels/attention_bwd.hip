@@ -3,7 +3,9 @@
 //   attn_bwd_dq_kernel    query-stationary. One workgroup = 128 queries (32 per wave),
 //                         walks the key tiles up to the diagonal like the forward:
 //                           S^T  = K . Q^T            (recompute, keys on registers)
-//                           P^T  = exp2(c S^T - LSE)  (the forward's LSE: no max, no sum)
+//                           P^T  = exp2(S'^T)         (S' = c S - LSE log2 e straight from the MFMA chain:
+//                                                      Q is pre-multiplied by c = scale log2 e and the row
+//                                                      constant is the accumulator's initial value)
 //                           dP^T = V . dO^T
 //                           dS^T = P^T (dP^T - delta)
 //                           dQ^T += K^T . dS^T        (K read transposed from LDS,
@@ -12,7 +14,8 @@
 //   attn_bwd_dkv_kernel   key-stationary. One workgroup = 128 keys (32 per wave, K and V
 //                         rows live in registers as MFMA B operands), walks the query
 //                         tiles from the diagonal to the end:
-//                           S  = Q . K^T - LSE/c   (row constant preloaded in the accumulator)
+//                           S' = Q . (c K)^T - LSE log2 e   (row constant preloaded in the accumulator,
+//                                                             K pre-multiplied by c: P = exp2(S'))
 //                           dP = dO . V^T - delta  (idem)
 //                           dV^T += dO^T . P ,  dK^T += Q^T . dS
 //                         Q and dO tiles are read by rows for S / dP and transposed for
@@ -93,7 +96,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   const float delta = lane_pair_sum(dpart);
   const float lse2 = lse[(int64_t(b) * H + head) * T + q_ld] * kLog2e;
   if (h == 0 && q_row < T) delta_out[(int64_t(b) * H + head) * T + q_row] = delta;
+  // The softmax works in exp2 units: P = exp2(c S - LSE log2 e), c = scale * log2 e. Both constants are
+  // moved out of the tile loop: this lane's Q fragments are multiplied by c once (rounded to bf16 like
+  // Q itself) and -LSE log2 e is the initial value of the S accumulator, so the MFMA chain ends as the
+  // exponent and a probability costs one v_exp_f32 (a packed multiply-add per pair less per tile).
   const float c = scale * kLog2e;
+#pragma unroll
+  for (int ks = 0; ks < kKSteps; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)((float)qf[ks][e] * c);
 
   f32x16 dq_acc[kDBlocks];
 #pragma unroll
@@ -128,8 +139,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          s_acc[kb][i] = 0.f;
-          dp_acc[kb][i] = -delta;  // row constant preloaded: the chain ends as dP - delta
+          s_acc[kb][i] = -lse2;    // row constants preloaded: the chains end as c S - LSE log2 e
+          dp_acc[kb][i] = -delta;  // and dP - delta
         }
 #pragma unroll
         for (int ks = 0; ks < kKSteps; ++ks) {
@@ -146,14 +157,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       const bool diag = key0 + kBN - 1 > q0;  // wave-uniform
       // dS^T = P^T (dP^T - delta), without the softmax scale. Two elements per packed fp32
       // instruction; the causal mask is only evaluated on tiles that straddle the diagonal.
-      const f32x2 c2 = {c, c}, l2 = {lse2, lse2};
       auto softmax_grad = [&](auto masked) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
-            const f32x2 e = f32x2{s_acc[kb][i], s_acc[kb][i + 1]} * c2 - l2;
-            f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            f32x2 p = {__builtin_amdgcn_exp2f(s_acc[kb][i]), __builtin_amdgcn_exp2f(s_acc[kb][i + 1])};
             if (decltype(masked)::value) {
               if (key0 + kb * 32 + acc_row(i, h) > q_row) p[0] = 0.f;
               if (key0 + kb * 32 + acc_row(i + 1, h) > q_row) p[1] = 0.f;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   constexpr int kKSteps = D / 16;
   constexpr int kDBlocks = D / 32;
   constexpr int kTileBytes = kBN * D * 2;
-  // [2][Q tile | dO tile], then [2][64 x (-LSE/scale) | 64 x (-delta)] fp32 row constants
+  // [2][Q tile | dO tile], then [2][64 x (-LSE log2 e) | 64 x (-delta)] fp32 row constants
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rowc = reinterpret_cast<float*>(smem + 4 * kTileBytes);
 
@@ -252,12 +261,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   const int key_ld = key < T ? key : T - 1;
   const bool wave_active = key0 < T;
 
-  // K and V rows as B operands: lane (key r, h) holds row[16*ks + 8*h .. +7].
+  // K and V rows as B operands: lane (key r, h) holds row[16*ks + 8*h .. +7]. The K fragments only feed
+  // the score product, so they carry the softmax's exp2 factor c = scale * log2 e (applied once here,
+  // rounded to bf16 like K itself): with -LSE log2 e preloaded in the accumulator the S chain ends as
+  // the exponent itself.
+  const float c = scale * kLog2e;
   bf16x8 kf[kKSteps], vf[kKSteps];
 #pragma unroll
   for (int ks = 0; ks < kKSteps; ++ks) {
     kf[ks] = *reinterpret_cast<const bf16x8*>(k_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
     vf[ks] = *reinterpret_cast<const bf16x8*>(v_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kf[ks][e] = (__bf16)((float)kf[ks][e] * c);
   }
   // Pin the arrival of the K / V fragments before the tile loop: waited for at their first use
   // inside it, the wait lands at the loop header, where the compiler cannot tell them from the
@@ -275,19 +290,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       dk_acc[i][j] = 0.f;
       dv_acc[i][j] = 0.f;
     }
-  const float c = scale * kLog2e;
-  const float inv_scale = 1.f / scale;  // LSE (natural log of sum exp(scale*S)) in raw-score units
 
   // Query tiles: from the one holding the workgroup's first key to the end.
   const int first_tile = (kt * kBM) / kBN;
   const int n_tiles = (T + kBN - 1) / kBN;
 
-  // Threads 0..63 stage -LSE/scale, threads 64..127 stage -delta of the tile's 64 queries. The
+  // Threads 0..63 stage -LSE log2 e, threads 64..127 stage -delta of the tile's 64 queries. The
   // load returns the raw value and the arithmetic happens when it is written to LDS a tile later:
   // computing at load time makes the compiler wait for the load — and, the counter being in
   // order, for the tile loads issued just before it — at the top of every iteration.
   const float* rowc_src = tid < 64 ? lse_row : delta_row;
-  const float rowc_mul = tid < 64 ? -inv_scale : -1.f;
+  const float rowc_mul = tid < 64 ? -kLog2e : -1.f;
   auto load_rowc = [&](int tile) -> float {
     if (tid >= 128) return 0.f;
     int q = tile * kBN + (tid & 63);
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         float neg_delta[kDrop ? 16 : 1];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          // chains end as S - LSE/scale (so exp2(c * acc) = P) and dP - delta
+          // chains end as c S - LSE log2 e (so exp2(acc) = P) and dP - delta
           const f32x4 a = *reinterpret_cast<const f32x4*>(rc + sub * 32 + 8 * g + 4 * h);
           const f32x4 d = *reinterpret_cast<const f32x4*>(rc + 64 + sub * 32 + 8 * g + 4 * h);
 #pragma unroll
@@ -350,7 +363,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         // P and dS = P (dP - delta), two elements per packed fp32 instruction. Only tiles on the
         // diagonal or past the end of the sequence evaluate the mask (separate code paths:
         // folded into one, the per-element compares ran on every tile).
-        const f32x2 c2 = {c, c};
         // Dropout: the forward multiplied V by keep * P / (1 - p). dV takes that dropped P; dS is
         // the undropped P times (keep * dP / (1 - p) - delta). keep_mask bit i = element i kept.
         uint32_t keep_mask = 0xffffu;
@@ -360,8 +372,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         auto softmax_grad = [&](auto masked) {
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
-            const f32x2 e = f32x2{s_acc[i], s_acc[i + 1]} * c2;
-            f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            f32x2 p = {__builtin_amdgcn_exp2f(s_acc[i]), __builtin_amdgcn_exp2f(s_acc[i + 1])};
             if (decltype(masked)::value) {
               const int q = qs + acc_row(i, h);
               if (q < key || q >= T) p[0] = 0.f;
