@@ -29,4 +29,10 @@ rm -rf $O/prof
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_wgrad -- python3 $R/tools/wgrad_pmc.py > $O/pmc_wgrad.log 2>&1 || exit 1
 python3 $R/tools/pmc_summary.py $O/pmc_wgrad > $O/pmc_wgrad_summary.txt 2>&1
 rm -rf $O/pmc_wgrad
+# effective shader clock per kernel (power throttling shows here, not in cycle counters)
+timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/clk -- python3 $R/bench.py --steps 3 --warmup 2 > $O/clk.log 2>&1 || exit 1
+python3 $R/tools/kernel_clock.py $O/clk/*/*counter_collection.csv $O/clk/*/*kernel_trace.csv > $O/kernel_clocks.txt 2>&1
+rm -rf $O/clk
+[ -x $R/tools/micro/bin/stream_probe ] && timeout -k 10 120 $R/tools/micro/bin/stream_probe > $O/stream_probe.log 2>&1
+cd $R && timeout -k 10 250 $TR --master-port 29753 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode fsdp --fsdp-resident-gb auto > $O/bench_large_world1_forced_fsdp_resident_auto.json 2>> $O/bench.err || exit 1
 echo collected
