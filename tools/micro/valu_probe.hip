@@ -61,7 +61,7 @@ __global__ void probe(float* out, unsigned long long* cycles, int iters) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 32; i += 8) acc ^= __float_as_uint(p[i]);
+      for (int i = 0; i < 32; ++i) acc ^= __float_as_uint(p[i]);  // every value stays live (32 v_xor on top)
     }
 #pragma unroll
     for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(s[i]));  // a fresh dependency per iteration, no extra instruction
