@@ -69,6 +69,46 @@ def test_fsdp_three_ranks_padding():
     run_distributed(_fsdp_grads_and_training, world=3, args=("FULL_SHARD", 1, 1))
 
 
+def _fsdp_resident_budget(rank, world):
+    """FULL_SHARD with a resident budget at two ranks: same training as without one, fewer all-gathers,
+    everything resharded at the end of every backward; 'auto' agrees on a budget across the ranks
+    (zero on CPU tensors) and behaves like plain FULL_SHARD."""
+    from pytorch_distributed_amd.optim import FusedAdamW
+    from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
+
+    base = _tiny_model(6)
+    plain = fsdp_wrap_gpt(copy.deepcopy(base), ShardingStrategy.FULL_SHARD)
+    kept = fsdp_wrap_gpt(copy.deepcopy(base), ShardingStrategy.FULL_SHARD, resident_gb=1.0)
+    auto = fsdp_wrap_gpt(copy.deepcopy(base), ShardingStrategy.FULL_SHARD, resident_gb="auto")
+    opts = [FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.1) for m in (plain, kept, auto)]
+
+    def gathers(m):
+        return sum(u.unit.num_allgathers for u in m.modules() if type(u).__name__ == "FSDP")
+
+    for step in range(2):
+        x, y = _batch(700 + step, 2 * world)
+        xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
+        before = [gathers(m) for m in (plain, kept, auto)]
+        for m, o in zip((plain, kept, auto), opts):
+            m(xs, ys).backward()
+            assert all(not u.unit.is_unsharded() for u in m.modules() if type(u).__name__ == "FSDP")
+            o.step(zero_grad=True)
+        n_blocks = len(base.transformer.h)
+        assert kept.resident_units == n_blocks and auto.resident_units == 0
+        # plain / auto: root + every block in forward, every block again in backward; kept: forward only
+        assert gathers(plain) - before[0] == 1 + 2 * n_blocks
+        assert gathers(auto) - before[2] == 1 + 2 * n_blocks
+        assert gathers(kept) - before[1] == 1 + n_blocks
+    for a, b in zip(plain.parameters(), kept.parameters()):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+    for a, b in zip(plain.parameters(), auto.parameters()):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_fsdp_resident_budget_two_ranks():
+    run_distributed(_fsdp_resident_budget, world=2)
+
+
 def _fsdp_state_dict_roundtrip(rank, world):
     ref = _tiny_model(4)
     model = _wrap(copy.deepcopy(ref), "FULL_SHARD")
