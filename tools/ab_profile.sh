@@ -2,6 +2,9 @@
 # A/B of two builds on one box: kernel traces of bench.py from the working tree and from the baseline
 # tree (.base_tree, a checkout of an earlier commit with its own built extension), then plain timed
 # runs alternating between the two. usage: tools/ab_profile.sh [extra bench.py args]
+# The baseline tree is made on the build machine before the GPU call:
+#   git worktree add --detach .base_tree <commit> && (cd .base_tree && python -m pytorch_distributed_amd._build)
+# (.base_tree is git-ignored; it travels to the GPU box with the rest of the working directory).
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ab
