@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
                                                            const bf16_raw* __restrict__ B, int64_t ldb,
                                                            float* __restrict__ c_partial,
                                                            float* __restrict__ bias_partial, int M, int I,
-                                                           int J, int S) {
+                                                           int J, int S, int i_fast) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -357,7 +357,11 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
   const int task = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
   const int slice = task / n_tiles;
   const int tile = task % n_tiles;
-  const int ti = tile / tiles_j, tj = tile % tiles_j;
+  // Consecutive tasks run together on one XCD and share its L2: walking the shorter side of the tile
+  // grid fastest keeps the set of distinct A and B blocks they stream per stage small (32 concurrent
+  // tasks of the 5 x 20 grid of a 1280 x 5120 gradient touch 12 blocks instead of 22: 392.6 -> 384.5 us
+  // at M = 32768; the 15 x 5 and 20 x 5 grids are already on their shorter side).
+  const int ti = i_fast ? tile % tiles_i : tile / tiles_j, tj = i_fast ? tile / tiles_i : tile % tiles_j;
 
   const int steps_total = M / kBM;
   const int step_lo = int(int64_t(steps_total) * slice / S);
@@ -870,7 +874,7 @@ bool wgrad_supported(int M, int I, int J) {
 void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c_partial,
                 float* bias_partial, int M, int I, int J, int S, hipStream_t stream) {
   const int n_tasks = ((I + kTile - 1) / kTile) * ((J + kTile - 1) / kTile) * S;
-  static int mode = -1, waves = 4, mfma = 32;
+  static int mode = -1, waves = 4, mfma = 32, order = -1;
   if (mode < 0) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel4<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)wgrad_kernel16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
@@ -881,6 +885,8 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    const char* o = getenv("PDA_WGRAD_ORDER");  // 0 / 1 force the j-fastest / i-fastest tile order (A/B measurements)
+    order = o ? atoi(o) : -1;
     const char* e = getenv("PDA_WGRAD_MODE");
     mode = e ? atoi(e) : 0;
   }
@@ -890,8 +896,10 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
     return;
   }
   if (waves == 4 && mode == 0) {
+    const int tiles_i = (I + kTile - 1) / kTile, tiles_j = (J + kTile - 1) / kTile;
+    const int i_fast = order < 0 ? (tiles_j > tiles_i) : order;
     hipLaunchKernelGGL(wgrad_kernel4<0>, dim3((unsigned)n_tasks), dim3(kThreads4), kStages * kStageBytes, stream,
-                       (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
+                       (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S, i_fast);
     return;
   }
   auto kern = mode == 1 ? wgrad_kernel<1> : mode == 2 ? wgrad_kernel<2> : wgrad_kernel<0>;
