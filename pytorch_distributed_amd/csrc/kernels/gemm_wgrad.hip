@@ -336,6 +336,17 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
 // always requested before the MFMAs of the current one are issued.
 constexpr int kThreads4 = 256;
 
+// Phase timing for tools/micro/wgrad_stamp.hip (which includes this file with PDA_WGRAD_STAMPS
+// defined): s_memtime ticks per wave summed over the stages of a task, in four phases. The value of a
+// stamp is only touched behind a wait the kernel performs anyway, so the schedule is the one that ships.
+#ifdef PDA_WGRAD_STAMPS
+__device__ unsigned long long g_wgrad_stamps[1024 * 4 * 8];  // [workgroup][wave][wait+barrier, k-step 0, fragment wait, k-step 1,
+                                                             //  start -> loop, loop, loop -> end, start (absolute)]
+#define PDA_STAMP(var) var = __builtin_amdgcn_s_memtime()
+#else
+#define PDA_STAMP(var)
+#endif
+
 template <int kUnused>
 __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __restrict__ A, int64_t lda,
                                                            const bf16_raw* __restrict__ B, int64_t ldb,
@@ -343,6 +354,9 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
                                                            float* __restrict__ bias_partial, int M, int I,
                                                            int J, int S, int i_fast) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PDA_WGRAD_STAMPS
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -441,6 +455,10 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
     for (int i = 0; i < 16; ++i) frag_read(0, 0, 0, i);
   }
 
+#ifdef PDA_WGRAD_STAMPS
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts2p = 0, ts3 = 0, sum_wait = 0, sum_k0 = 0, sum_frag = 0, sum_k1 = 0;
+#endif
   auto main_loop = [&](auto with_bias) {
     constexpr bool kBias = decltype(with_bias)::value;
     for (int t0 = 0; t0 < n_steps; t0 += kStages) {
@@ -451,9 +469,11 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
         // Stage t complete and k-step 0 of stage t+1 landed; the 12 younger loads stay in flight.
         // This wave's k-step 0 fragments (requested a stage ago) are awaited here as well, so that
         // the matrix pipe starts the moment the barrier opens.
+        PDA_STAMP(ts0);
         asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        PDA_STAMP(ts1);
         const unsigned a_tile = smem_base + u * kStageBytes;
 
         // ---- k-step 0: 16 MFMAs; in their shadow the 16 fragment reads of k-step 1 (two after
@@ -482,8 +502,20 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        PDA_STAMP(ts2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // k-step 1 fragments (and the bias rows)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef PDA_WGRAD_STAMPS
+        if (ts3 != 0) {  // ts3, ts2p: the previous stage's
+          sum_k1 += ts0 - ts3;
+          sum_frag += ts3 - ts2p;
+        }
+        ts2p = ts2;
+        sum_wait += ts1 - ts0;
+        sum_k0 += ts2 - ts1;
+        PDA_STAMP(ts3);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 
         // ---- k-step 1: 16 MFMAs; in their shadow the fragment reads of k-step 0 of stage t+1
         // (landed before this stage's barrier; after the last stage they fetch stale bytes that
@@ -519,6 +551,9 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy loads
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // the ring is reused below
+#ifdef PDA_WGRAD_STAMPS
+  const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
   // One accumulator tile at a time leaves the accumulator file (the fences keep the compiler from
   // moving all 256 values into ordinary registers at once, which it can only do by spilling).
@@ -550,6 +585,15 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
       if (ti * kTile + tid < I) bias_partial[int64_t(slice) * I + ti * kTile + tid] = s;
     }
   }
+#ifdef PDA_WGRAD_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial stores have left the wave
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long* g = g_wgrad_stamps + (blockIdx.x * 4 + wave) * 8;
+    g[0] = sum_wait, g[1] = sum_k0, g[2] = sum_frag, g[3] = sum_k1;
+    g[4] = t_loop - t_start, g[5] = t_loop_end - t_loop, g[6] = t_end - t_loop_end, g[7] = t_start;
+  }
+#endif
 }
 
 // ---- four-wave variant on 16 x 16 x 32 MFMAs ----------------------------------------------------
@@ -562,9 +606,15 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
 // isolation (c_fc 404 vs 411 us incl. the slice reduction), 1 % slower inside the training step
 // (306.6 vs 303.0 us average): per stage the 16 x 16 form leaves the instruction issue port 8 of every
 // 16 cycles instead of 24 of every 32, and the 32 fragment reads plus 8 LDS-DMA loads (tens of issue
-// cycles each) no longer fit the MFMAs' shadow. Both kernels sit near 1,900 cycles per stage against
-// 1,024 of matrix work: the operand feed (3.4 GB through L2 -> LDS per c_fc gradient), not the
-// matrix pipe or its clock, sets the pace. Opt-in (PDA_WGRAD_MFMA=16).
+// cycles each) no longer fit the MFMAs' shadow. Opt-in (PDA_WGRAD_MFMA=16).
+// Where the 32 x 32 x 16 kernel's time goes (tools/micro/wgrad_stamp.hip, s_memtime per phase; c_fc
+// gradient, back to back): a stage takes ~1,330 clock ticks against 1,024 of matrix work — the
+// k-step 0 block (16 MFMAs, 16 fragment reads, 8 LDS-DMA loads) 656, k-step 1 (16 MFMAs, 16 reads)
+// 579, the two waits ~100 after subtracting the stamps' own round trip — at a clock of 1.71 GHz
+// (2.4 nominal: power). The loop is 93 % of a task, the partial-tile stores 5 %. The L1 has 62 lines
+// in flight on average (it sustains 143 in tools/micro/feed_probe.hip) and the data of a stage lands
+// two stages ahead: neither the L2 -> LDS feed nor the counted waits hold the loop, the stalls sit
+// inside the MFMA blocks (fragment reads and DMA writes keep the LDS at ~75 B/cycle of its 128).
 //   * k order: lane group g (lane / 16) of an MFMA operand holds contraction slots 8g..8g+7; they are
 //     fed tile rows {4g..4g+3, 16+4g..16+4g+3} — any assignment works as long as both operands use the
 //     same one — so that the first transposed read of every fragment touches rows 0-15 and the second
@@ -852,6 +902,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 int wgrad_pick_slices(int M, int I, int J) {
   const int n_tiles = ((I + kTile - 1) / kTile) * ((J + kTile - 1) / kTile);
   const int steps = M / kBM;
+  static const int forced = getenv("PDA_WGRAD_SLICES") ? atoi(getenv("PDA_WGRAD_SLICES")) : 0;  // A/B measurements
+  if (forced > 0) return forced < steps ? forced : steps;
   int best = 1;
   double best_score = -1.0;
   for (int s = 1; s <= 16 && s <= steps; ++s) {
