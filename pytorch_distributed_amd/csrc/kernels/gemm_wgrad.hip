@@ -335,6 +335,14 @@ __global__ __launch_bounds__(kThreads) void wgrad_kernel(const bf16_raw* __restr
 // per SIMD means nothing hides latency but the schedule itself: fragments of the next k-step are
 // always requested before the MFMAs of the current one are issued.
 constexpr int kThreads4 = 256;
+#ifndef PDA_WGRAD_READS_PER_SLOT
+#define PDA_WGRAD_READS_PER_SLOT 2
+#endif
+#ifndef PDA_WGRAD_LOADS_PER_SLOT
+#define PDA_WGRAD_LOADS_PER_SLOT 1
+#endif
+constexpr int kReadsPerSlot = PDA_WGRAD_READS_PER_SLOT;  // fragment reads issued behind one MFMA
+constexpr int kLoadsPerSlot = PDA_WGRAD_LOADS_PER_SLOT;  // LDS-DMA loads issued behind one MFMA
 
 // Phase timing for tools/micro/wgrad_stamp.hip (which includes this file with PDA_WGRAD_STAMPS
 // defined): s_memtime ticks per wave summed over the stages of a task, in four phases. The value of a
@@ -488,11 +496,14 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           acc[i >> 2][i & 3] = mfma32(af[i >> 2], bfr[i & 3], acc[i >> 2][i & 3]);
-          if (i < 8) {
-            frag_read(1, 1, u, 2 * i);
-            frag_read(1, 1, u, 2 * i + 1);
-          } else {
-            issue_one(t + kStages - 1, (u + kStages - 1) % kStages, i - 8);
+          if (i < 16 / kReadsPerSlot) {
+#pragma unroll
+            for (int q = 0; q < kReadsPerSlot; ++q) frag_read(1, 1, u, kReadsPerSlot * i + q);
+          }
+          if (i >= 16 - 8 / kLoadsPerSlot) {
+#pragma unroll
+            for (int q = 0; q < kLoadsPerSlot; ++q)
+              issue_one(t + kStages - 1, (u + kStages - 1) % kStages, kLoadsPerSlot * (i - (16 - 8 / kLoadsPerSlot)) + q);
           }
           if (kBias) {  // column sums of the A tile: chunk (tid & 31) of rows (tid >> 5) + 8 j
             if (i == 8) bias_rows[0] = b128_read<0>(a_tile + bias_off);
@@ -528,9 +539,9 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           acc[i >> 2][i & 3] = mfma32(af[i >> 2], bfr[i & 3], acc[i >> 2][i & 3]);
-          if (i < 8) {
-            frag_read(0, 0, (u + 1) % kStages, 2 * i);
-            frag_read(0, 0, (u + 1) % kStages, 2 * i + 1);
+          if (i < 16 / kReadsPerSlot) {
+#pragma unroll
+            for (int q = 0; q < kReadsPerSlot; ++q) frag_read(0, 0, (u + 1) % kStages, kReadsPerSlot * i + q);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
