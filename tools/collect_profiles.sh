@@ -8,16 +8,20 @@ mkdir -p $O
 cd $R
 B="python bench.py --steps 10 --warmup 3"
 TR="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1"
-timeout -k 10 150 $B > $O/bench_large_single_mb32.json 2> $O/bench.err || exit 1
-timeout -k 10 150 $B --activation-checkpoint selective > $O/bench_large_single_mb32_selective.json 2>> $O/bench.err || exit 1
-timeout -k 10 150 $B --activation-checkpoint full > $O/bench_large_single_mb32_full.json 2>> $O/bench.err || exit 1
-timeout -k 10 150 $B --micro-batch 8 > $O/bench_large_single_mb8_dropout0.json 2>> $O/bench.err || exit 1
-timeout -k 10 150 $B --micro-batch 8 --dropout 0.1 > $O/bench_large_single_mb8_dropout0.1.json 2>> $O/bench.err || exit 1
-timeout -k 10 150 $B --model gpt2-medium > $O/bench_medium_single.json 2>> $O/bench.err || exit 1
-timeout -k 10 150 $B --model gpt2 > $O/bench_small_single.json 2>> $O/bench.err || exit 1
-timeout -k 10 200 $B --model gpt2-xl > $O/bench_xl_single.json 2>> $O/bench.err || exit 1
-timeout -k 10 250 $TR --master-port 29751 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both > $O/bench_large_world1_forced_ddp_fsdp.json 2>> $O/bench.err || exit 1
-timeout -k 10 250 $TR --master-port 29752 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both --model gpt2-medium > $O/bench_medium_world1_forced_ddp_fsdp.json 2>> $O/bench.err || exit 1
+M32="--batch-per-gpu 32 --micro-batch 32"
+timeout -k 10 250 $B > $O/bench_large_single_mb64.json 2> $O/bench.err || exit 1
+timeout -k 10 150 $B $M32 > $O/bench_large_single_mb32.json 2>> $O/bench.err || exit 1
+timeout -k 10 250 $B --activation-checkpoint selective > $O/bench_large_single_mb64_selective.json 2>> $O/bench.err || exit 1
+timeout -k 10 250 $B --activation-checkpoint full > $O/bench_large_single_mb64_full.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --batch-per-gpu 32 --micro-batch 8 > $O/bench_large_single_mb8_dropout0.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --batch-per-gpu 32 --micro-batch 8 --dropout 0.1 > $O/bench_large_single_mb8_dropout0.1.json 2>> $O/bench.err || exit 1
+timeout -k 10 200 $B --model gpt2-medium > $O/bench_medium_single_mb64.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --model gpt2-medium $M32 > $O/bench_medium_single_mb32.json 2>> $O/bench.err || exit 1
+timeout -k 10 150 $B --model gpt2 > $O/bench_small_single_mb64.json 2>> $O/bench.err || exit 1
+timeout -k 10 300 $B --model gpt2-xl > $O/bench_xl_single_mb64.json 2>> $O/bench.err || exit 1
+timeout -k 10 400 $TR --master-port 29751 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both > $O/bench_large_world1_forced_ddp_fsdp_mb64.json 2>> $O/bench.err || exit 1
+timeout -k 10 300 $TR --master-port 29753 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both $M32 > $O/bench_large_world1_forced_ddp_fsdp_mb32.json 2>> $O/bench.err || exit 1
+timeout -k 10 300 $TR --master-port 29752 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode both --model gpt2-medium > $O/bench_medium_world1_forced_ddp_fsdp_mb64.json 2>> $O/bench.err || exit 1
 timeout -k 10 100 python tools/wgrad_probe.py > $O/wgrad_probe.log 2>&1 || exit 1
 PDA_WGRAD_WAVES=8 timeout -k 10 100 python tools/wgrad_probe.py > $O/wgrad_probe_eight_wave.log 2>&1 || exit 1
 timeout -k 10 60 python tools/attn_time.py > $O/attention_time.log 2>&1 || exit 1
@@ -38,5 +42,5 @@ rm -rf $O/clk
 for probe in feed_probe mfma_probe wgrad_stamp; do
   [ -x $R/tools/micro/bin/$probe ] && { timeout -k 10 120 $R/tools/micro/bin/$probe > $O/$probe.log 2>&1 || exit 1; }
 done
-cd $R && timeout -k 10 250 $TR --master-port 29753 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode fsdp --fsdp-resident-gb auto > $O/bench_large_world1_forced_fsdp_resident_auto.json 2>> $O/bench.err || exit 1
+cd $R && timeout -k 10 400 $TR --master-port 29754 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode fsdp --fsdp-resident-gb auto > $O/bench_large_world1_forced_fsdp_resident_auto.json 2>> $O/bench.err || exit 1
 echo collected

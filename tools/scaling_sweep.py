@@ -62,8 +62,8 @@ def main():
     ap.add_argument("--modes", nargs="*", default=["ddp", "fsdp:FULL_SHARD", "fsdp:SHARD_GRAD_OP", "fsdp:NO_SHARD"])
     ap.add_argument("--model", default="gpt2-large")
     ap.add_argument("--seq-len", type=int, default=1024)
-    ap.add_argument("--batch-per-gpu", type=int, default=32)
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--micro-batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--timeout", type=int, default=900)
