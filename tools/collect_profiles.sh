@@ -39,7 +39,7 @@ python3 $R/tools/kernel_clock.py $O/clk/*/*counter_collection.csv $O/clk/*/*kern
 rm -rf $O/clk
 [ -x $R/tools/micro/bin/stream_probe ] && timeout -k 10 120 $R/tools/micro/bin/stream_probe > $O/stream_probe.log 2>&1
 # operand-feed, MFMA-issue and weight-gradient phase probes (built on the CPU box beforehand, see each file's header)
-for probe in feed_probe mfma_probe wgrad_stamp; do
+for probe in feed_probe mfma_probe coexec_probe wgrad_stamp; do
   [ -x $R/tools/micro/bin/$probe ] && { timeout -k 10 120 $R/tools/micro/bin/$probe > $O/$probe.log 2>&1 || exit 1; }
 done
 cd $R && timeout -k 10 400 $TR --master-port 29754 bench.py --gpus 1 --steps 10 --warmup 3 --wrap-single --mode fsdp --fsdp-resident-gb auto > $O/bench_large_world1_forced_fsdp_resident_auto.json 2>> $O/bench.err || exit 1

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../.."
 mkdir -p tools/micro/bin
-for p in stream_probe valu_probe feed_probe mfma_probe; do
+for p in stream_probe valu_probe feed_probe mfma_probe coexec_probe; do
   hipcc --offload-arch=gfx950 -O3 -o tools/micro/bin/$p tools/micro/$p.hip
 done
 hipcc --offload-arch=gfx950 -O3 -I pytorch_distributed_amd/csrc/kernels -o tools/micro/bin/wgrad_stamp tools/micro/wgrad_stamp.hip
