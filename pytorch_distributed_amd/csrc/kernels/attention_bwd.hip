@@ -26,6 +26,15 @@
 // dK and dV of a key are summed inside one wave and dQ of a query inside one wave, so the
 // result is deterministic. The price is recomputing S and dP in both kernels (7 matrix
 // products instead of 5); the alternative single-kernel form needs fp32 atomics for dQ.
+//
+// What bounds them: on gfx950 the matrix pipe and the vector ALU of a SIMD do not work at the
+// same time to any useful degree (tools/micro/coexec_probe.hip, mfma_probe.hip: beside a wave
+// issuing MFMAs back to back a second wave gets about one vector instruction per MFMA, and
+// inside one wave eight v_fma_f32 behind an MFMA cost 37 extra ticks). A SIMD therefore spends the
+// SUM of the tile's matrix work (24 MFMAs of 32 ticks per wave) and vector work (per probability
+// one v_exp_f32, half a v_pk_mul_f32, one or two halves of a v_cvt_pk_bf16_f32) however the two
+// are scheduled; the kernels keep the vector part at that minimum (both row constants ride in the
+// accumulators' initial values, the softmax scale is folded into an operand once per kernel).
 #include "attention_common.h"
 #include "pda_kernels.h"
 
