@@ -202,8 +202,9 @@ def main():
         """Builds the model wrapped as ``kind`` and times K steps. Returns the result fields."""
         model = build_model()
         detail = {}
-        if distributed and args.dtype == "bf16":
-            # GEMM algorithm / layout decisions: measured once on the bare model, rank 0's adopted by all
+        if args.dtype == "bf16":
+            # GEMM algorithm / layout decisions: measured once on the bare model before anything is timed or
+            # wrapped (also with --warmup 0 no kernel search falls into a timed step), rank 0's adopted by all
             from pytorch_distributed_amd.parallel import plan_sync
             plan_sync.plan_gemms(model, args.micro_batch, args.seq_len, cfg.vocab_size)
         if kind == "ddp":
