@@ -128,6 +128,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # read when the HIP runtime starts (see the package's __init__)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
