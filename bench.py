@@ -19,6 +19,12 @@ GPT-2 Large for backward in 108 GB, and the 65,536-row GEMMs, the weight-gradien
 once-per-step optimizer and gradient traffic all amortise better than at 32 (measured: 42.2 % MFU
 against 40.1-40.9 % at 32; 96 and 128 add nothing more).
 
+Besides the headline the same process measures the REFERENCE'S OWN RECIPE — 32 sequences per GPU as
+4 micro-batches of 8 with selective activation checkpointing (train_baseline.py:24-31,
+model/my_gpt2.py:175-181) — for a few steps and reports it under ``reference_recipe`` in the same JSON
+line (``--no-reference-recipe`` skips it), so the like-for-like number sits next to the one sized for
+the hardware.
+
 Modes (``--mode``): ``single`` (one GPU, no wrapper), ``ddp``, ``fsdp`` (``--strategy``), ``both`` =
 DDP then FSDP measured back to back in the same job. Defaults: ``single`` for one GPU, ``both`` for
 several; with ``both`` the headline ``value`` is FSDP's and the line carries a ``modes`` table with
@@ -76,7 +82,13 @@ def parse_args(argv=None):
     ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="none",
                     help="none keeps every activation (fastest, default here); selective rebuilds element-wise "
                          "activations in backward (the reference's default policy); full re-runs each block")
-    ap.add_argument("--no-tuned-gemms", action="store_true", help="library-default GEMM solution selection")
+    ap.add_argument("--no-reference-recipe", action="store_true",
+                    help="skip the second, short measurement at the reference's recipe (32 = 4 x 8, selective)")
+    ap.add_argument("--reference-steps", type=int, default=5, help="timed steps of the reference-recipe measurement")
+    ap.add_argument("--comm-dual", choices=["auto", "on", "off"], default="auto",
+                    help="second RCCL communicator for the all-gather queue: auto = created on multi-GPU jobs and "
+                         "used only when the start-up measurement finds an all-gather behind a reduce-scatter faster "
+                         "that way")
     ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",
                     help="single GPU, experimental: record the whole optimizer step into a HIP graph and replay it")
@@ -93,28 +105,69 @@ def _free_port() -> int:
 
 def launch_ranks(args) -> int:
     """Parent mode: start ``args.gpus`` ranks as a child job and relay its single result line.
-    Nothing in this process has initialised a GPU (no HIP call happens before this point)."""
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+    Nothing in this process has initialised a GPU (no HIP call happens before this point).
 
-    def run(extra):
+    Up to three attempts, each a fresh job, so that one wrong guess about the machine cannot lose
+    the measurement: (1) the native communicator with the dmabuf IPC switch the multi-process RCCL
+    transport needs on dmabuf-only hosts (``HSA_ENABLE_IPC_MODE_LEGACY=0`` unless the caller set the
+    variable); (2) the same environment on the torch.distributed backend; (3) that backend with the
+    variable as the caller had it (unset = the runtime's legacy IPC path). Every attempt and why the
+    next one was made is recorded under ``launch_attempts`` in the result line."""
+    base_env = dict(os.environ)
+    base_env.setdefault("OMP_NUM_THREADS", "4")
+    caller_set_ipc = "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+    dmabuf_env = dict(base_env)
+    dmabuf_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def run(extra, env):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
                *sys.argv[1:], *extra]
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
         return proc.returncode, [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
 
-    code, lines = run([])
-    if not lines and args.comm == "auto":
-        # The ranks died before any of them could vote for the fallback (a crash inside the collective
-        # library rather than an error): one more job on the torch.distributed group.
-        print("[bench] no result from the native communicator job (exit %d); retrying with --comm c10d" % code,
-              file=sys.stderr, flush=True)
-        code, lines = run(["--comm", "c10d"])
+    plan = [("native communicator, HSA_ENABLE_IPC_MODE_LEGACY=%s" % dmabuf_env["HSA_ENABLE_IPC_MODE_LEGACY"], [], dmabuf_env)]
+    if args.comm == "auto":
+        plan.append(("torch.distributed backend, same environment", ["--comm", "c10d"], dmabuf_env))
+        if not caller_set_ipc:
+            plan.append(("torch.distributed backend, HSA_ENABLE_IPC_MODE_LEGACY unset", ["--comm", "c10d"], base_env))
+    attempts, code, lines = [], 1, []
+    for what, extra, env in plan:
+        code, lines = run(extra, env)
+        attempts.append({"attempt": what, "exit_code": code, "result": bool(lines)})
+        if lines:
+            break
+        print(f"[bench] no result from: {what} (exit {code})", file=sys.stderr, flush=True)
     if lines:
-        print(lines[-1], flush=True)
-    return code
+        try:
+            rec = json.loads(lines[-1])
+            rec["launch_attempts"] = attempts
+            print(json.dumps(rec), flush=True)
+        except ValueError:
+            print(lines[-1], flush=True)
+    return code if lines else (code or 1)
+
+
+def run_modes(kinds, measure, communicator_state):
+    """Measures every kind in ``kinds`` with ``measure(kind)``. With several kinds a failure in one
+    must not lose the other's number: the exception is recorded as that kind's ``error`` and the
+    loop goes on — unless ``communicator_state()`` reports that the communicator is gone or was
+    aborted (a collective that timed out aborts it on every rank), after which nothing further can
+    be measured. Returns ``(results, good_kinds)``."""
+    results = {}
+    for k in kinds:
+        if len(kinds) == 1:
+            results[k] = measure(k)
+            continue
+        try:
+            results[k] = measure(k)
+        except Exception as exc:  # noqa: BLE001 - reported in the result line
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            results[k] = {"parallelism": k, "error": repr(exc)[:500]}
+            if communicator_state() in ("none", "aborted"):
+                break
+    return results, [k for k in kinds if k in results and "error" not in results[k]]
 
 
 def main():
@@ -128,12 +181,14 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # read when the HIP runtime starts (see the package's __init__)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    from pytorch_distributed_amd.parallel.comm import prepare_multiprocess_env
+    prepare_multiprocess_env()  # the IPC switch of a multi-rank job, before the HIP runtime starts
 
     import torch
 
@@ -149,11 +204,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    tuned = False
-    if not args.no_tuned_gemms:
-        from pytorch_distributed_amd.tuning import enable_tuned_gemms
-        tuned = enable_tuned_gemms()
-
+    comm.RELAUNCH_STDOUT_FD = real_stdout  # a rank relaunched on the fallback backend prints the line there
     mode = args.mode
     if mode == "auto":
         mode = "both" if world > 1 else ("fsdp" if args.wrap_single else "single")
@@ -177,19 +228,22 @@ def main():
 
     policy = None
     if distributed:
+        dual = args.comm_dual == "on" or (args.comm_dual == "auto" and world > 1)
         comm.init_distributed(backend="c10d" if args.comm == "c10d" else "rccl", timeout_s=300.0,
-                              fallback="c10d" if args.comm == "auto" else None)
+                              fallback="c10d" if args.comm == "auto" else None, dual=dual)
         if world > 1 and not args.no_comm_autotune:
             policy = autotune.tune(device=device, total_grad_bytes=n_params * (2 if args.dtype == "bf16" else 4),
                                    verbose=True)
+        c0 = comm.get_communicator()
+        if args.comm_dual == "auto" and policy is None and getattr(c0, "has_dual", lambda: False)():
+            c0.set_dual_route(False)  # nothing was measured: the shared communicator, the long-standing route
 
-    def build_model():
+    def build_model(activation_checkpoint):
         import contextlib
         torch.manual_seed(42)
         torch.cuda.manual_seed(42)
-        kw = {} if is_llama else {"activation_checkpoint": args.activation_checkpoint}
         with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
-            m = cls(cfg, **kw)
+            m = cls(cfg, activation_checkpoint=activation_checkpoint)
         return m.to(device=device, dtype=dtype)
 
     def fence():
@@ -199,15 +253,18 @@ def main():
         if distributed:
             comm.barrier()
 
-    def measure(kind: str) -> dict:
-        """Builds the model wrapped as ``kind`` and times K steps. Returns the result fields."""
-        model = build_model()
+    def measure(kind: str, batch_per_gpu=args.batch_per_gpu, micro_batch=args.micro_batch,
+                activation_checkpoint=args.activation_checkpoint, steps=args.steps, warmup=args.warmup) -> dict:
+        """Builds the model wrapped as ``kind`` and times ``steps`` optimizer steps of ``batch_per_gpu``
+        sequences per GPU in micro-batches of ``micro_batch``. Returns the result fields."""
+        accum = batch_per_gpu // micro_batch
+        model = build_model(activation_checkpoint)
         detail = {}
         if args.dtype == "bf16":
             # GEMM algorithm / layout decisions: measured once on the bare model before anything is timed or
             # wrapped (also with --warmup 0 no kernel search falls into a timed step), rank 0's adopted by all
             from pytorch_distributed_amd.parallel import plan_sync
-            plan_sync.plan_gemms(model, args.micro_batch, args.seq_len, cfg.vocab_size)
+            plan_sync.plan_gemms(model, micro_batch, args.seq_len, cfg.vocab_size)
         if kind == "ddp":
             from pytorch_distributed_amd.parallel import DDP
             decompose = {"auto": None, "on": True, "off": False}[args.ddp_decompose]
@@ -232,7 +289,7 @@ def main():
         else:
             parallelism = "single"
         optimizer = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.1, capturable=args.hip_graph)
-        loader = iter(SyntheticTokenLoader(args.micro_batch, args.seq_len, cfg.vocab_size, device, seed=1234 + rank))
+        loader = iter(SyntheticTokenLoader(micro_batch, args.seq_len, cfg.vocab_size, device, seed=1234 + rank))
         model.train()
 
         def one_step():
@@ -247,7 +304,7 @@ def main():
 
         if args.hip_graph:
             from pytorch_distributed_amd.utils.graphs import GraphedTrainStep
-            graphed = GraphedTrainStep(model, optimizer, args.micro_batch, args.seq_len, accum, warmup_steps=2)
+            graphed = GraphedTrainStep(model, optimizer, micro_batch, args.seq_len, accum, warmup_steps=2)
 
             def one_step():  # noqa: F811 - replaces the eager step above
                 xs, ys = zip(*(next(loader) for _ in range(accum)))
@@ -256,11 +313,11 @@ def main():
             for _ in range(3):  # 2 eager warm-up steps + the capture happen before the timed region
                 one_step()
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             one_step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             one_step()
         fence()
         elapsed = time.perf_counter() - t0
@@ -268,9 +325,9 @@ def main():
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             comm.all_reduce(t, "max")
             elapsed = float(t.item())
-        tokens_per_step = args.batch_per_gpu * world * args.seq_len
-        tps = tokens_per_step * args.steps / elapsed
-        out = {"parallelism": parallelism, "value": tps, "ms_per_step": 1e3 * elapsed / args.steps,
+        tokens_per_step = batch_per_gpu * world * args.seq_len
+        tps = tokens_per_step * steps / elapsed
+        out = {"parallelism": parallelism, "value": tps, "ms_per_step": 1e3 * elapsed / steps,
                "mfu": tps * fpt / (world * MI355X_PEAK_BF16_FLOPS), "tflops_per_gpu": tps * fpt / world / 1e12,
                "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2**30, **detail}
         del model, optimizer, loader, one_step
@@ -281,28 +338,29 @@ def main():
         torch.cuda.reset_peak_memory_stats(device)
         return out
 
+    def communicator_state() -> str:
+        c = comm.get_communicator()
+        return "none" if c is None else ("aborted" if getattr(c, "aborted", False) else "ok")
+
     kinds = {"single": ["single"], "ddp": ["ddp"], "fsdp": ["fsdp"], "both": ["ddp", "fsdp"]}[mode]
-    results = {}
-    for k in kinds:
-        if len(kinds) == 1:
-            results[k] = measure(k)
-            continue
-        # Two modes in one job: a failure in one must not lose the other's number. Every rank sees the
-        # same exception class of failure (a collective that times out aborts the communicator on all
-        # of them), and after an abort nothing further can be measured.
-        try:
-            results[k] = measure(k)
-        except Exception as exc:  # noqa: BLE001 - reported in the result line
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            results[k] = {"parallelism": k, "error": repr(exc)[:500]}
-            c = comm.get_communicator()
-            if c is None or getattr(c, "aborted", False):
-                break
-    good = [k for k in kinds if k in results and "error" not in results[k]]
+    results, good = run_modes(kinds, measure, communicator_state)
     if not good:
         raise SystemExit(f"no mode could be measured: {results}")
     head = results[good[-1]]  # FSDP when both were measured
+
+    # The reference's own recipe, like for like, in the same process and wrapper as the headline.
+    reference = None
+    if not args.no_reference_recipe and not args.hip_graph and communicator_state() != "aborted":
+        try:
+            reference = measure(good[-1], batch_per_gpu=32, micro_batch=8, activation_checkpoint="selective",
+                                steps=args.reference_steps, warmup=2)
+            reference.update({"global_batch": 32 * world, "micro_batch": 8, "grad_accum": 4, "seq_len": args.seq_len,
+                              "activation_checkpoint": "selective", "steps": args.reference_steps, "warmup": 2,
+                              "recipe": "assignments/assignment1/train_baseline.py:24-31 (per GPU), dropout 0"})
+        except Exception as exc:  # noqa: BLE001 - the headline stands on its own
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            reference = {"error": repr(exc)[:500]}
 
     if rank == 0:
         global_batch = args.batch_per_gpu * world
@@ -310,13 +368,22 @@ def main():
                   "grad_accum": accum, "seq_len": args.seq_len, "parallelism": head["parallelism"],
                   "dropout": args.dropout, "activation_checkpoint": args.activation_checkpoint,
                   "optimizer": "fused AdamW lr=3e-4 wd=0.1, fp32 master + state",
-                  "flops_per_token": fpt, "tuned_gemm_table": tuned, "hip_graph": bool(args.hip_graph)}
+                  "flops_per_token": fpt, "hip_graph": bool(args.hip_graph)}
+        if args.dtype == "bf16":
+            from pytorch_distributed_amd import _ext
+            table = _ext.require().gemm_planner_stats()["table"]
+            config["gemm_planner"] = {"problems": len(table),
+                                      "library_default_kept": sum(1 for r in table if int(r[7]) == 0)}
         if distributed:
             c = comm.get_communicator()
             config["comm_backend"] = c.backend
+            if hasattr(c, "has_dual") and c.has_dual():
+                config["comm_dual_route"] = bool(c.dual_route())
             if policy is not None:
                 config["comm_policy"] = {"ddp_bucket_mb": policy.ddp_bucket_mb, "ddp_decompose": policy.ddp_decompose,
                                          "fsdp_unit_mb": policy.fsdp_unit_mb, "source": policy.source,
+                                         "dual_route": policy.dual_route,
+                                         "gather_behind_reduce_us": policy.gather_behind_reduce_us,
                                          "fits_us_GBps": {k: [round(a * 1e6, 1), round(b / 1e9, 1)]
                                                           for k, (a, b) in policy.fits.items()}}
         line = {
@@ -329,6 +396,8 @@ def main():
         }
         if len(results) > 1 or distributed:
             line["modes"] = results
+        if reference is not None:
+            line["reference_recipe"] = reference
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if args.planner_stats and rank == 0:

@@ -6,14 +6,7 @@ and sharded data parallelism (FSDP: flat-parameter units with all-gather /
 reduce-scatter prefetch; FULL_SHARD, SHARD_GRAD_OP, NO_SHARD), with the
 training-step hot ops as hand-written gfx950 HIP kernels.
 """
-import os as _os
-
-# Sharing device memory between the ranks of a node (RCCL's intra-node transport) needs dmabuf IPC on hosts whose
-# driver no longer offers the legacy path; the switch is read when the HIP runtime starts, so it is set on import,
-# before anything touches a GPU. An explicit setting in the environment wins.
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-from . import _ext  # noqa: E402,F401
+from . import _ext  # noqa: F401
 
 __version__ = "0.1.0"
 

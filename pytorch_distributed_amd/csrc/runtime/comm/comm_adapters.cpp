@@ -8,10 +8,21 @@
 //                          (kind, elements, queue) per collective, in issue order. Tests assert
 //                          exact collective sequences on it (prefetch order, "no_sync issues
 //                          nothing"), and the trace tools use the log to label collectives.
+//   HangingCommunicator    fault injection: forwards to an inner communicator until a chosen
+//                          number of collectives has been issued; the next one never completes (a
+//                          peer that died mid-collective). It owns a Watchdog like the RCCL
+//                          communicator's, so the whole failure path — poll, time-out, abort, the
+//                          blocked caller raising, every later collective raising — runs on a
+//                          CPU without a GPU or a second process.
 #include "communicator.h"
+#include "watchdog.h"
 
 #include <c10/util/Exception.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace pda {
 namespace comm {
@@ -196,6 +207,98 @@ class RecordingCommunicator final : public Communicator {
   std::mutex log_mu_;
   std::vector<RecordedCall> log_;
 };
+
+namespace {
+
+class HungWork final : public Work {
+ public:
+  explicit HungWork(std::shared_ptr<std::atomic<bool>> aborted) : aborted_(std::move(aborted)) {}
+  void wait() override { synchronize(); }  // a CPU collective's wait() blocks the host
+  void synchronize() override {
+    while (!aborted_->load()) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    TORCH_CHECK(false, "communicator was aborted (a collective timed out or a peer failed)");
+  }
+  bool completed() override { return false; }
+
+ private:
+  std::shared_ptr<std::atomic<bool>> aborted_;
+};
+
+class HangingCommunicator final : public Communicator {
+ public:
+  HangingCommunicator(std::shared_ptr<Communicator> inner, int64_t healthy_calls, double timeout_s)
+      : inner_(std::move(inner)), healthy_left_(healthy_calls), aborted_(std::make_shared<std::atomic<bool>>(false)) {
+    TORCH_CHECK(inner_, "HangingCommunicator: null inner communicator");
+    watchdog_ = std::make_unique<Watchdog>(
+        timeout_s,
+        [this](const std::string& what, double age) {
+          fprintf(stderr, "[pda.comm] rank %d: %s has not completed after %.1f s; aborting the communicator\n",
+                  inner_->rank(), what.c_str(), age);
+          abort();
+        },
+        nullptr, /*poll_ms=*/20);
+  }
+  ~HangingCommunicator() override { watchdog_->stop(); }
+  int rank() const override { return inner_->rank(); }
+  int world() const override { return inner_->world(); }
+  std::string backend() const override { return "hanging:" + inner_->backend(); }
+  bool on_gpu() const override { return inner_->on_gpu(); }
+  bool aborted() const override { return aborted_->load(); }
+
+  std::shared_ptr<Work> all_reduce(const at::Tensor& t, RedOp op, Queue q) override {
+    if (auto w = maybe_hang("all_reduce")) return w;
+    return inner_->all_reduce(t, op, q);
+  }
+  std::shared_ptr<Work> all_gather(const at::Tensor& out, const at::Tensor& in, Queue q) override {
+    if (auto w = maybe_hang("all_gather")) return w;
+    return inner_->all_gather(out, in, q);
+  }
+  std::shared_ptr<Work> reduce_scatter(const at::Tensor& out, const at::Tensor& in, RedOp op, Queue q) override {
+    if (auto w = maybe_hang("reduce_scatter")) return w;
+    return inner_->reduce_scatter(out, in, op, q);
+  }
+  std::shared_ptr<Work> broadcast(const at::Tensor& t, int root, Queue q) override {
+    if (auto w = maybe_hang("broadcast")) return w;
+    return inner_->broadcast(t, root, q);
+  }
+  void barrier() override {
+    check();
+    inner_->barrier();
+  }
+  void close() override {
+    watchdog_->stop();
+    inner_->close();
+  }
+  void abort() override {
+    bool expected = false;
+    if (!aborted_->compare_exchange_strong(expected, true)) return;
+    inner_->abort();
+  }
+  std::vector<std::string> exchange(const std::string& mine) override { return inner_->exchange(mine); }
+
+ private:
+  void check() const {
+    TORCH_CHECK(!aborted_->load(), "communicator was aborted (a collective timed out or a peer failed)");
+  }
+  std::shared_ptr<Work> maybe_hang(const char* what) {
+    check();
+    if (healthy_left_.fetch_sub(1) > 0) return nullptr;
+    auto w = std::make_shared<HungWork>(aborted_);
+    watchdog_->watch([] { return false; }, what);
+    return w;
+  }
+  std::shared_ptr<Communicator> inner_;
+  std::atomic<int64_t> healthy_left_;
+  std::shared_ptr<std::atomic<bool>> aborted_;
+  std::unique_ptr<Watchdog> watchdog_;
+};
+
+}  // namespace
+
+std::shared_ptr<Communicator> make_hanging_communicator(std::shared_ptr<Communicator> inner, int64_t healthy_calls,
+                                                        double timeout_s) {
+  return std::make_shared<HangingCommunicator>(std::move(inner), healthy_calls, timeout_s);
+}
 
 std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg) {
   return std::make_shared<C10dCommunicator>(std::move(pg));

@@ -2,20 +2,30 @@
 //
 // Streams. The communicator owns two HIP streams, one per Queue. Together with the caller's
 // compute stream that is three of the four hardware queues a process gets, so collectives never
-// share a hardware queue with compute kernels and an all-gather for the next unit is never
-// stuck behind a reduce-scatter of the previous one.
+// share a hardware queue with compute kernels.
+//
+// Library communicators. One ncclComm serves both queues by default: RCCL then runs the
+// collectives in issue order whatever stream they are on, so a backward all-gather prefetch
+// queues behind the reduce-scatter issued before it. With `dual` a SECOND ncclComm (its own
+// unique id through the store) serves the gather queue and the two traffic classes really run
+// concurrently; whether gathers use it is a run-time switch (set_dual_route) so the start-up
+// autotuner can time an all-gather behind a large reduce-scatter both ways and keep the faster
+// (parallel/autotune.py). Every rank issues the same collectives in the same order on each
+// communicator, which is what makes two communicators on two streams safe.
 //
 // Fences. issue(): an event recorded on the caller's stream is awaited by the queue's stream
 // (the collective sees every kernel enqueued before it), the RCCL call is enqueued, and a
 // completion event is recorded behind it. Work::wait() makes the then-current stream wait on
 // that completion event. No host thread ever blocks in the steady state.
 //
-// Failure handling. A watchdog thread polls the completion events of outstanding
+// Failure handling. A watchdog thread (watchdog.h) polls the completion events of outstanding
 // collectives; one that stays incomplete for longer than the timeout (a peer died, a rank
 // took a different branch) gets the communicator aborted with ncclCommAbort, which ends the
-// stuck kernels, and every later call on it raises.
+// stuck kernels (and releases the library communicator's resources: an aborted communicator is
+// not destroyed a second time), and every later call on it raises.
 #include "communicator.h"
 #include "store.h"
+#include "watchdog.h"
 
 #include <c10/hip/HIPStream.h>
 #include <c10/util/Exception.h>
@@ -24,10 +34,8 @@
 
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
 #include <thread>
 
 namespace pda {
@@ -117,13 +125,27 @@ class RcclWork final : public Work {
   RcclWork(std::shared_ptr<PooledEvent> done, int device, std::vector<at::Tensor> keep,
            std::shared_ptr<std::atomic<bool>> aborted)
       : done_(std::move(done)), device_(device), keep_(std::move(keep)), aborted_(std::move(aborted)) {}
+  // A handle dropped without wait() (a logged scalar nobody read) would hand its buffers back to the
+  // caching allocator's pool of the COMPUTE stream while the queue's stream may still be writing
+  // them: hold them until the collective has completed. Rare, so blocking the host is fine; after
+  // an abort or at interpreter exit the event call just fails and nothing is waited for.
+  ~RcclWork() override {
+    if (!waited_ && !aborted_->load()) (void)hipEventSynchronize(done_->event);
+  }
   void wait() override {
     hipStream_t cur = c10::hip::getCurrentHIPStream((c10::DeviceIndex)device_).stream();
     PDA_HIP(hipStreamWaitEvent(cur, done_->event, 0));
+    waited_ = true;
     check();
   }
   void synchronize() override {
-    PDA_HIP(hipEventSynchronize(done_->event));
+    // Polls rather than blocking in hipEventSynchronize: an aborted communicator's stuck kernel may
+    // never signal the event, and the caller must get the error instead of a hang.
+    while (hipEventQuery(done_->event) != hipSuccess) {
+      check();
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    waited_ = true;
     check();
   }
   bool completed() override { return hipEventQuery(done_->event) == hipSuccess; }
@@ -136,28 +158,17 @@ class RcclWork final : public Work {
   int device_;
   std::vector<at::Tensor> keep_;  // buffers stay allocated at least as long as the handle
   std::shared_ptr<std::atomic<bool>> aborted_;
+  bool waited_ = false;
 };
 
 class RcclCommunicator final : public Communicator {
  public:
-  RcclCommunicator(std::shared_ptr<Rendezvous> rv, int device, double timeout_s)
+  RcclCommunicator(std::shared_ptr<Rendezvous> rv, int device, double timeout_s, bool dual)
       : rv_(std::move(rv)), device_(device), timeout_s_(timeout_s), pool_(std::make_shared<EventPool>()),
         aborted_(std::make_shared<std::atomic<bool>>(false)) {
     rank_ = rv_->rank;
     world_ = rv_->world;
     PDA_HIP(hipSetDevice(device_));
-    ncclUniqueId id;
-    std::memset(&id, 0, sizeof(id));
-    static int generation = 0;  // several communicators per process get distinct ids
-    const std::string key = "rccl/unique_id/" + std::to_string(generation++);
-    if (rank_ == 0) {
-      PDA_NCCL(ncclGetUniqueId(&id));
-      if (rv_->client) rv_->client->set(key, std::string(reinterpret_cast<const char*>(&id), sizeof(id)));
-    } else {
-      const std::string bytes = rv_->client->get(key);
-      TORCH_CHECK(bytes.size() == sizeof(id), "communicator: malformed RCCL unique id in the store");
-      std::memcpy(&id, bytes.data(), sizeof(id));
-    }
     // The streams are created BEFORE the library initialises, at normal priority. Measured on this
     // stack (ROCm 7.0 runtime, RCCL 2.26): the first high-priority stream created after
     // ncclCommInitRank stops draining as soon as it exchanges more than a couple of event fences with
@@ -174,41 +185,48 @@ class RcclCommunicator final : public Communicator {
         else PDA_HIP(hipStreamCreateWithFlags(&streams_[q], hipStreamNonBlocking));
       }
     }
-    PDA_NCCL(ncclCommInitRank(&comm_, world_, id, rank_));
+    comms_[0].store(init_library_communicator());
+    if (dual) {
+      comms_[1].store(init_library_communicator());
+      dual_route_.store(true);
+    }
     int version = 0;
     (void)ncclGetVersion(&version);
     version_ = version;
     const char* wd = std::getenv("PDA_COMM_WATCHDOG");
-    use_watchdog_ = !(wd != nullptr && wd[0] == '0');
-    if (use_watchdog_) watchdog_ = std::thread([this] { watch(); });
+    if (!(wd != nullptr && wd[0] == '0'))
+      watchdog_ = std::make_unique<Watchdog>(
+          timeout_s_,
+          [this](const std::string& what, double age) {
+            fprintf(stderr,
+                    "[pda.comm] rank %d: %s has not completed after %.0f s; aborting the communicator "
+                    "(a peer died or the ranks issued different collectives)\n",
+                    rank_, what.c_str(), age);
+            abort();
+          },
+          [this] { (void)hipSetDevice(device_); });
   }
 
   ~RcclCommunicator() override { close(); }
 
   void close() override {
-    {
-      std::lock_guard<std::mutex> lock(watch_mu_);
-      if (closed_) return;
-      closed_ = true;
-      stop_ = true;
-    }
-    watch_cv_.notify_all();
-    if (watchdog_.joinable()) watchdog_.join();
+    if (closed_.exchange(true)) return;
+    if (watchdog_) watchdog_->stop();
     std::lock_guard<std::mutex> lock(mu_);
-    if (comm_ != nullptr) {
-      if (!aborted_->load()) {  // abort() already tore the library communicator down
-        (void)hipSetDevice(device_);
-        for (auto s : streams_)
-          if (s) (void)hipStreamSynchronize(s);
-        (void)ncclCommDestroy(comm_);
-      }
-      comm_ = nullptr;
+    const bool was_aborted = aborted_->load();
+    if (!was_aborted) {
+      (void)hipSetDevice(device_);
+      for (auto s : streams_)
+        if (s) (void)hipStreamSynchronize(s);
+    }
+    for (auto& c : comms_) {
+      ncclComm_t lib = c.exchange(nullptr);
+      if (lib != nullptr && !was_aborted) (void)ncclCommDestroy(lib);  // abort() already released it
     }
     for (auto& s : streams_) {
       if (s) (void)hipStreamDestroy(s);
       s = nullptr;
     }
-    watched_.clear();
   }
 
   int rank() const override { return rank_; }
@@ -218,30 +236,36 @@ class RcclCommunicator final : public Communicator {
   bool aborted() const override { return aborted_->load(); }
   int version() const { return version_; }
   int64_t stream_handle(int q) const { return (int64_t)(uintptr_t)streams_[q]; }
+  bool has_dual() const { return comms_[1].load() != nullptr; }
+  bool dual_route() const { return dual_route_.load(); }
+  void set_dual_route(bool on) {
+    TORCH_CHECK(!on || has_dual(), "communicator was created without a second library communicator");
+    dual_route_.store(on);
+  }
 
   std::shared_ptr<Work> all_reduce(const at::Tensor& t, RedOp op, Queue q) override {
     check_collective_args("all_reduce", t, t, 1, true);
     count(Kind::kAllReduce, t);
-    return issue(q, {t}, "all_reduce", [&](hipStream_t s) {
+    return issue(q, {t}, "all_reduce", [&](ncclComm_t comm, hipStream_t s) {
       PDA_NCCL(ncclAllReduce(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), nccl_dtype(t.scalar_type()), nccl_op(op),
-                             comm_, s));
+                             comm, s));
     });
   }
 
   std::shared_ptr<Work> all_gather(const at::Tensor& out, const at::Tensor& in, Queue q) override {
     check_collective_args("all_gather", out, in, world_, true);
     count(Kind::kAllGather, out);
-    return issue(q, {out, in}, "all_gather", [&](hipStream_t s) {
-      PDA_NCCL(ncclAllGather(in.data_ptr(), out.data_ptr(), (size_t)in.numel(), nccl_dtype(in.scalar_type()), comm_, s));
+    return issue(q, {out, in}, "all_gather", [&](ncclComm_t comm, hipStream_t s) {
+      PDA_NCCL(ncclAllGather(in.data_ptr(), out.data_ptr(), (size_t)in.numel(), nccl_dtype(in.scalar_type()), comm, s));
     });
   }
 
   std::shared_ptr<Work> reduce_scatter(const at::Tensor& out, const at::Tensor& in, RedOp op, Queue q) override {
     check_collective_args("reduce_scatter", in, out, world_, true);
     count(Kind::kReduceScatter, in);
-    return issue(q, {out, in}, "reduce_scatter", [&](hipStream_t s) {
+    return issue(q, {out, in}, "reduce_scatter", [&](ncclComm_t comm, hipStream_t s) {
       PDA_NCCL(ncclReduceScatter(in.data_ptr(), out.data_ptr(), (size_t)out.numel(), nccl_dtype(in.scalar_type()),
-                                 nccl_op(op), comm_, s));
+                                 nccl_op(op), comm, s));
     });
   }
 
@@ -249,34 +273,52 @@ class RcclCommunicator final : public Communicator {
     check_collective_args("broadcast", t, t, 1, true);
     TORCH_CHECK(root >= 0 && root < world_, "broadcast: bad root ", root);
     count(Kind::kBroadcast, t);
-    return issue(q, {t}, "broadcast", [&](hipStream_t s) {
-      PDA_NCCL(ncclBroadcast(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), nccl_dtype(t.scalar_type()), root, comm_, s));
+    return issue(q, {t}, "broadcast", [&](ncclComm_t comm, hipStream_t s) {
+      PDA_NCCL(ncclBroadcast(t.data_ptr(), t.data_ptr(), (size_t)t.numel(), nccl_dtype(t.scalar_type()), root, comm, s));
     });
   }
 
   void barrier() override { rv_->barrier("rccl"); }
 
-  std::vector<std::string> exchange(const std::string& mine) override {
-    if (world_ <= 1 || !rv_->client) return {mine};
-    const std::string base = "xchg/rccl/" + std::to_string(exchange_seq_++) + "/";
-    rv_->client->set(base + std::to_string(rank_), mine);
-    std::vector<std::string> out;
-    for (int r = 0; r < world_; ++r) out.push_back(r == rank_ ? mine : rv_->client->get(base + std::to_string(r)));
-    return out;
-  }
+  std::vector<std::string> exchange(const std::string& mine) override { return rv_->exchange("rccl", mine); }
 
+  // Callable from any thread, also while another thread is inside an RCCL call on this
+  // communicator (that is what ncclCommAbort is for), hence no lock: the pointers are atomics and
+  // the first caller wins.
   void abort() override {
     bool expected = false;
     if (!aborted_->compare_exchange_strong(expected, true)) return;
-    if (comm_ != nullptr) (void)ncclCommAbort(comm_);
+    for (auto& c : comms_) {
+      ncclComm_t lib = c.load();
+      if (lib != nullptr) (void)ncclCommAbort(lib);
+    }
   }
 
  private:
+  ncclComm_t init_library_communicator() {
+    ncclUniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    static std::atomic<int> generation{0};  // several communicators per process get distinct ids
+    const std::string key = "rccl/unique_id/" + std::to_string(generation++);
+    if (rank_ == 0) {
+      PDA_NCCL(ncclGetUniqueId(&id));
+      if (rv_->client) rv_->client->set(key, std::string(reinterpret_cast<const char*>(&id), sizeof(id)));
+    } else {
+      const std::string bytes = rv_->client->get(key);
+      TORCH_CHECK(bytes.size() == sizeof(id), "communicator: malformed RCCL unique id in the store");
+      std::memcpy(&id, bytes.data(), sizeof(id));
+    }
+    ncclComm_t lib = nullptr;
+    PDA_NCCL(ncclCommInitRank(&lib, world_, id, rank_));
+    return lib;
+  }
+
   template <typename F>
   std::shared_ptr<Work> issue(Queue q, std::vector<at::Tensor> keep, const char* what, F&& launch) {
     TORCH_CHECK(!aborted_->load(), "communicator was aborted (a collective timed out or a peer failed)");
-    std::lock_guard<std::mutex> lock(mu_);  // RCCL calls on one communicator are serialised
-    TORCH_CHECK(comm_ != nullptr, "communicator is closed");
+    std::lock_guard<std::mutex> lock(mu_);  // RCCL calls of one process are serialised
+    ncclComm_t lib = comms_[q == Queue::kGather && dual_route_.load() ? 1 : 0].load();
+    TORCH_CHECK(lib != nullptr, "communicator is closed");
     int prev = 0;
     PDA_HIP(hipGetDevice(&prev));
     if (prev != device_) PDA_HIP(hipSetDevice(device_));
@@ -287,74 +329,41 @@ class RcclCommunicator final : public Communicator {
       PDA_HIP(hipEventRecord(ready.event, cur));
       PDA_HIP(hipStreamWaitEvent(s, ready.event, 0));
     }
-    launch(s);
+    launch(lib, s);
     auto done = std::make_shared<PooledEvent>(pool_);
     PDA_HIP(hipEventRecord(done->event, s));
     if (prev != device_) PDA_HIP(hipSetDevice(prev));
-    if (use_watchdog_) {
-      std::lock_guard<std::mutex> wl(watch_mu_);
-      watched_.push_back({done, now_s(), what});
-    }
+    if (watchdog_) watchdog_->watch([done] { return hipEventQuery(done->event) == hipSuccess; }, what);
     return std::make_shared<RcclWork>(std::move(done), device_, std::move(keep), aborted_);
-  }
-
-  struct Watched {
-    std::shared_ptr<PooledEvent> done;
-    double issued;
-    const char* what;
-  };
-
-  void watch() {
-    (void)hipSetDevice(device_);
-    std::unique_lock<std::mutex> lock(watch_mu_);
-    while (!stop_) {
-      watch_cv_.wait_for(lock, std::chrono::milliseconds(watched_.empty() ? 1000 : 250));
-      if (stop_) break;
-      const double now = now_s();
-      while (!watched_.empty()) {
-        Watched& w = watched_.front();
-        if (hipEventQuery(w.done->event) == hipSuccess) {
-          watched_.pop_front();
-          continue;
-        }
-        if (timeout_s_ > 0 && now - w.issued > timeout_s_) {
-          fprintf(stderr,
-                  "[pda.comm] rank %d: %s has not completed after %.0f s; aborting the communicator "
-                  "(a peer died or the ranks issued different collectives)\n",
-                  rank_, w.what, now - w.issued);
-          lock.unlock();
-          abort();
-          lock.lock();
-          watched_.clear();
-        }
-        break;  // collectives of one queue complete in order; younger ones are re-checked next round
-      }
-    }
   }
 
   std::shared_ptr<Rendezvous> rv_;
   int device_, rank_ = 0, world_ = 1, version_ = 0;
   double timeout_s_;
-  ncclComm_t comm_ = nullptr;
+  std::atomic<ncclComm_t> comms_[2] = {nullptr, nullptr};  // [1]: the gather queue's own, when dual
+  std::atomic<bool> dual_route_{false};
   hipStream_t streams_[2] = {nullptr, nullptr};
   std::shared_ptr<EventPool> pool_;
   std::shared_ptr<std::atomic<bool>> aborted_;
   std::mutex mu_;
-  int64_t exchange_seq_ = 0;
-
-  std::thread watchdog_;
-  std::mutex watch_mu_;
-  std::condition_variable watch_cv_;
-  std::deque<Watched> watched_;
-  bool stop_ = false;
-  bool closed_ = false;
-  bool use_watchdog_ = true;
+  std::atomic<bool> closed_{false};
+  std::unique_ptr<Watchdog> watchdog_;
 };
 
 }  // namespace
 
-std::shared_ptr<Communicator> make_rccl_communicator(std::shared_ptr<Rendezvous> rv, int device, double timeout_s) {
-  return std::make_shared<RcclCommunicator>(std::move(rv), device, timeout_s);
+std::shared_ptr<Communicator> make_rccl_communicator(std::shared_ptr<Rendezvous> rv, int device, double timeout_s,
+                                                     bool dual) {
+  return std::make_shared<RcclCommunicator>(std::move(rv), device, timeout_s, dual);
+}
+
+// dual_route: -1 = query only, 0 / 1 = route gathers to the shared / the second library communicator.
+// Returns {has second communicator, gathers currently use it}.
+std::pair<bool, bool> rccl_dual_route(const std::shared_ptr<Communicator>& c, int set) {
+  auto* r = dynamic_cast<RcclCommunicator*>(c.get());
+  if (r == nullptr) return {false, false};
+  if (set >= 0) r->set_dual_route(set != 0);
+  return {r->has_dual(), r->dual_route()};
 }
 
 int64_t rccl_stream_handle(const std::shared_ptr<Communicator>& c, int q) {

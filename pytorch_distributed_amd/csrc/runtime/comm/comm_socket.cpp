@@ -92,7 +92,14 @@ class SocketCommunicator final : public Communicator {
     const std::string base = "sock/" + std::to_string(generation++) + "/";
     int lfd = net::listen_on("", 0, world_);
     TORCH_CHECK(lfd >= 0, "socket communicator: cannot listen");
-    rv_->client->set(base + std::to_string(rank_), rv_->client->local_address() + ":" + std::to_string(net::bound_port(lfd)));
+    // The address peers reach this rank by: the local end of its connection to the store — except
+    // when that is a loopback address although rank 0 was named otherwise (rank 0 talking to its own
+    // server that listens on every interface): peers on other nodes then need the master's name.
+    std::string my_addr = rv_->client->local_address();
+    const bool loop = my_addr.rfind("127.", 0) == 0 || my_addr == "::1";
+    const std::string& mh = rv_->master_host;
+    if (rank_ == 0 && loop && !mh.empty() && mh.rfind("127.", 0) != 0 && mh != "localhost" && mh != "::1") my_addr = mh;
+    rv_->client->set(base + std::to_string(rank_), my_addr + ":" + std::to_string(net::bound_port(lfd)));
     for (int p = 0; p < rank_; ++p) {  // connect downwards
       const std::string addr = rv_->client->get(base + std::to_string(p));
       const size_t colon = addr.rfind(':');
@@ -191,14 +198,7 @@ class SocketCommunicator final : public Communicator {
 
   void barrier() override { rv_->barrier("sock"); }
 
-  std::vector<std::string> exchange(const std::string& mine) override {
-    if (world_ <= 1) return {mine};
-    const std::string base = "xchg/sock/" + std::to_string(exchange_seq_++) + "/";
-    rv_->client->set(base + std::to_string(rank_), mine);
-    std::vector<std::string> out;
-    for (int r = 0; r < world_; ++r) out.push_back(r == rank_ ? mine : rv_->client->get(base + std::to_string(r)));
-    return out;
-  }
+  std::vector<std::string> exchange(const std::string& mine) override { return rv_->exchange("sock", mine); }
 
   void abort() override {
     aborted_ = true;

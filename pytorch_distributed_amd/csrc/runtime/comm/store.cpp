@@ -5,6 +5,7 @@
 //   SET  u8 1, u32 klen, key, u32 vlen, value             -> u8 1
 //   GET  u8 2, u32 klen, key                              -> u32 vlen, value   (parked until set)
 //   ADD  u8 3, u32 klen, key, i64 delta                   -> i64 new value
+//   DEL  u8 4, u32 klen, prefix                           -> u8 1   (every key starting with prefix)
 #include "store.h"
 
 #include <arpa/inet.h>
@@ -26,7 +27,7 @@ namespace comm {
 
 namespace {
 constexpr char kMagic[8] = {'P', 'D', 'A', 'S', 'T', 'O', 'R', '1'};
-enum Op : uint8_t { kSet = 1, kGet = 2, kAdd = 3 };
+enum Op : uint8_t { kSet = 1, kGet = 2, kAdd = 3, kDel = 4 };
 
 double now_s() {
   using namespace std::chrono;
@@ -60,23 +61,39 @@ void set_nodelay(int fd) {
   setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
 }
 
-int listen_on(const std::string& host, int port, int backlog) {
-  // Listen on every interface: peers may reach this rank through an address other than the
-  // one the name resolves to locally.
-  (void)host;
-  int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-  if (fd < 0) throw std::runtime_error("store: socket() failed");
-  int one = 1;
-  setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-  sockaddr_in addr{};
-  addr.sin_family = AF_INET;
-  addr.sin_addr.s_addr = htonl(INADDR_ANY);
-  addr.sin_port = htons((uint16_t)port);
-  if (::bind(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) != 0 || ::listen(fd, backlog) != 0) {
+int listen_on(const std::string& host, int port, int backlog, std::string* bound_host) {
+  // First choice: the one address `host` names, so the port is not open on interfaces nobody was
+  // told about. When the name does not resolve to an IPv4 address of this machine (a virtual IP,
+  // a name that only peers resolve) the bind fails with EADDRNOTAVAIL and every interface is used.
+  if (bound_host) bound_host->clear();
+  for (int attempt = host.empty() ? 1 : 0; attempt < 2; ++attempt) {
+    sockaddr_in addr{};
+    addr.sin_family = AF_INET;
+    addr.sin_addr.s_addr = htonl(INADDR_ANY);
+    addr.sin_port = htons((uint16_t)port);
+    if (attempt == 0) {
+      sockaddr_storage ss{};
+      socklen_t len = 0;
+      if (!resolve(host, port, &ss, &len) || ss.ss_family != AF_INET) continue;
+      addr.sin_addr = reinterpret_cast<sockaddr_in*>(&ss)->sin_addr;
+    }
+    int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) throw std::runtime_error("store: socket() failed");
+    int one = 1;
+    setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    if (::bind(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) == 0 && ::listen(fd, backlog) == 0) {
+      if (attempt == 0 && bound_host) {
+        char buf[INET_ADDRSTRLEN] = {0};
+        inet_ntop(AF_INET, &addr.sin_addr, buf, sizeof(buf));
+        *bound_host = buf;
+      }
+      return fd;
+    }
+    const int err = errno;
     ::close(fd);
-    return -1;
+    if (attempt == 0 && err == EADDRINUSE) return -1;  // the port is taken on that address: next port
   }
-  return fd;
+  return -1;
 }
 
 int bound_port(int fd) {
@@ -164,7 +181,7 @@ std::string local_address(int fd) {
 StoreServer::StoreServer(const std::string& host, int base_port, int scan, std::string job_id)
     : job_id_(std::move(job_id)) {
   for (int i = 0; i < scan && listen_fd_ < 0; ++i) {
-    listen_fd_ = net::listen_on(host, base_port + i, 256);
+    listen_fd_ = net::listen_on(host, base_port + i, 256, &bound_host_);
     if (listen_fd_ >= 0) port_ = base_port + i;
   }
   if (listen_fd_ < 0)
@@ -189,6 +206,11 @@ StoreServer::~StoreServer() {
   ::close(wake_fd_[1]);
 }
 
+size_t StoreServer::num_keys() {
+  std::lock_guard<std::mutex> lock(data_mu_);
+  return data_.size();
+}
+
 void StoreServer::answer_waiters(const std::string& key) {
   auto it = waiters_.find(key);
   if (it == waiters_.end()) return;
@@ -205,6 +227,7 @@ void StoreServer::answer_waiters(const std::string& key) {
 }
 
 bool StoreServer::consume(Client& c) {
+  std::lock_guard<std::mutex> data_lock(data_mu_);
   auto& in = c.in;
   size_t pos = 0;
   auto need = [&](size_t n) { return in.size() - pos >= n; };
@@ -267,6 +290,12 @@ bool StoreServer::consume(Client& c) {
       data_[key] = std::string(reinterpret_cast<const char*>(&cur), 8);
       net::send_all(c.fd, &cur, 8);
       answer_waiters(key);
+    } else if (op == kDel) {
+      pos = p;
+      for (auto it = data_.lower_bound(key); it != data_.end() && it->first.compare(0, key.size(), key) == 0;)
+        it = data_.erase(it);
+      const uint8_t ok = 1;
+      net::send_all(c.fd, &ok, 1);
     } else {
       return false;
     }
@@ -396,14 +425,42 @@ int64_t StoreClient::add(const std::string& key, int64_t delta) {
   return v;
 }
 
+void StoreClient::erase_prefix(const std::string& prefix) {
+  std::lock_guard<std::mutex> lock(mu_);
+  std::string req(1, (char)kDel);
+  put_str(req, prefix);
+  net::send_all(fd_, req.data(), req.size());
+  uint8_t ok = 0;
+  net::recv_all(fd_, &ok, 1, timeout_s_);
+}
+
 std::string StoreClient::local_address() const { return net::local_address(fd_); }
 
 // ---------------------------------------------------------------------------------- rendezvous
 void Rendezvous::barrier(const std::string& tag) {
   if (world <= 1 || !client) return;
-  const std::string base = "barrier/" + tag + "/" + std::to_string(barrier_seq++);
-  if (client->add(base + "/count", 1) == world) client->set(base + "/done", "1");
+  const int64_t seq = barrier_seq++;
+  const std::string base = "barrier/" + tag + "/" + std::to_string(seq);
+  if (client->add(base + "/count", 1) == world) {
+    // Last to arrive: every rank has entered round `seq`, so every rank has left round seq - 1
+    // (its `done` was read) and those two keys can go.
+    if (seq > 0) client->erase_prefix("barrier/" + tag + "/" + std::to_string(seq - 1) + "/");
+    client->set(base + "/done", "1");
+  }
   (void)client->get(base + "/done");
+}
+
+std::vector<std::string> Rendezvous::exchange(const std::string& tag, const std::string& mine) {
+  if (world <= 1 || !client) return {mine};
+  const int64_t seq = exchange_seq++;
+  const std::string base = "xchg/" + tag + "/" + std::to_string(seq) + "/";
+  client->set(base + std::to_string(rank), mine);
+  std::vector<std::string> out;
+  for (int r = 0; r < world; ++r) out.push_back(r == rank ? mine : client->get(base + std::to_string(r)));
+  // Having read every rank's entry of this round, every rank has begun it and therefore finished
+  // reading the round before: that round's entries have no reader left (rank 0 drops them).
+  if (seq > 0 && rank == 0) client->erase_prefix("xchg/" + tag + "/" + std::to_string(seq - 1) + "/");
+  return out;
 }
 
 std::shared_ptr<Rendezvous> rendezvous_from_env(int rank, int world, const std::string& host, int port, double timeout_s,
@@ -411,13 +468,14 @@ std::shared_ptr<Rendezvous> rendezvous_from_env(int rank, int world, const std::
   auto rv = std::make_shared<Rendezvous>();
   rv->rank = rank;
   rv->world = world;
+  rv->master_host = host;
   if (world <= 1) return rv;
   constexpr int kScan = 16;
   if (rank == 0) rv->server = std::make_unique<StoreServer>(host, port, kScan, job_id);
-  // Rank 0 talks to its own server through the loopback interface.
-  rv->client = std::make_unique<StoreClient>(rank == 0 ? std::string("127.0.0.1") : host,
-                                             rank == 0 ? rv->server->port() : port, rank == 0 ? 1 : kScan, job_id,
-                                             timeout_s);
+  // Rank 0 reaches its own server by the address it bound (loopback when it listens everywhere).
+  const std::string own = rank == 0 && !rv->server->bound_host().empty() ? rv->server->bound_host() : "127.0.0.1";
+  rv->client = std::make_unique<StoreClient>(rank == 0 ? own : host, rank == 0 ? rv->server->port() : port,
+                                             rank == 0 ? 1 : kScan, job_id, timeout_s);
   return rv;
 }
 

@@ -3,12 +3,16 @@
 // One rank (rank 0) hosts a StoreServer thread; every rank, rank 0 included, talks to it
 // through a StoreClient over TCP. It carries what a communicator needs before it exists:
 // the RCCL unique id, the listening addresses of the CPU socket mesh, barriers and small
-// agreement checks. Blocking `get` (the server parks the request until the key is set) and
-// an atomic `add` are the only primitives beyond `set`.
+// agreement checks. Blocking `get` (the server parks the request until the key is set), an
+// atomic `add` and a prefix `erase` are the only primitives beyond `set`. Barriers and
+// exchanges erase the keys of the round before the one that just completed, so a long run
+// (one exchange per collective under PDA_COMM_DEBUG=1) keeps rank 0's map at a few entries.
 //
 // Address: MASTER_ADDR, port MASTER_PORT + 1 by default (MASTER_PORT itself belongs to the
-// launcher's own store). When that port is taken, rank 0 walks upwards and the clients
-// find the right server through the handshake, which carries a job identifier.
+// launcher's own store). The server listens on the address MASTER_ADDR resolves to (every
+// interface only when that address cannot be bound locally). When the port is taken, rank 0
+// walks upwards and the clients find the right server through the handshake, which carries a
+// job identifier.
 //
 // Role in the reference: the TCPStore rendezvous hidden inside
 // dist.init_process_group(backend='nccl') (assignments/assignment1/train_ddp.py:23-24).
@@ -28,7 +32,9 @@ namespace comm {
 
 // Small socket helpers shared by the store and the CPU socket communicator.
 namespace net {
-int listen_on(const std::string& host, int port, int backlog);  // returns fd or -1 (port in use)
+// Listens on `host`'s address (empty, unresolvable or not local: every interface). Returns fd or -1
+// (port in use); `*bound_host` receives the numeric address that was bound, "" for every interface.
+int listen_on(const std::string& host, int port, int backlog, std::string* bound_host = nullptr);
 int bound_port(int fd);
 int connect_to(const std::string& host, int port, double timeout_s);  // retries until the deadline; -1 on failure
 void send_all(int fd, const void* data, size_t n);
@@ -43,6 +49,8 @@ class StoreServer {
   StoreServer(const std::string& host, int base_port, int scan, std::string job_id);
   ~StoreServer();
   int port() const { return port_; }
+  const std::string& bound_host() const { return bound_host_; }  // "" = every interface
+  size_t num_keys();  // entries currently held (tests: the map stays bounded)
 
  private:
   struct Client {
@@ -54,7 +62,8 @@ class StoreServer {
   bool consume(Client& c);  // parses as many complete requests as `c.in` holds; false = drop client
   void answer_waiters(const std::string& key);
 
-  std::string job_id_;
+  std::string job_id_, bound_host_;
+  std::mutex data_mu_;  // num_keys() reads the map from another thread
   int listen_fd_ = -1, wake_fd_[2] = {-1, -1}, port_ = 0;
   std::thread thread_;
   std::atomic<bool> stop_{false};
@@ -72,6 +81,7 @@ class StoreClient {
   void set(const std::string& key, const std::string& value);
   std::string get(const std::string& key);  // blocks until the key exists (or the timeout passes)
   int64_t add(const std::string& key, int64_t delta);
+  void erase_prefix(const std::string& prefix);  // drops every key that starts with `prefix`
   std::string local_address() const;
   double timeout_s() const { return timeout_s_; }
 
@@ -88,8 +98,11 @@ struct Rendezvous {
   std::unique_ptr<StoreServer> server;  // rank 0 only
   std::unique_ptr<StoreClient> client;  // nullptr when world == 1
   int rank = 0, world = 1;
-  int64_t barrier_seq = 0;
+  std::string master_host;  // the address peers reach rank 0 by
+  std::atomic<int64_t> barrier_seq{0}, exchange_seq{0};
   void barrier(const std::string& tag);
+  // Every rank contributes a byte string and receives all of them in rank order.
+  std::vector<std::string> exchange(const std::string& tag, const std::string& mine);
 };
 
 std::shared_ptr<Rendezvous> rendezvous_from_env(int rank, int world, const std::string& host, int port, double timeout_s,

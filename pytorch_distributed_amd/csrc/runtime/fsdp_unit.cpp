@@ -96,10 +96,15 @@ class ShardedRuntime;
 
 class ShardedUnit {
  public:
+  // accum_fp32: the unit's unsharded gradient buffer is fp32 although the parameters are not, so
+  // the micro-batches of a no_sync window (and the slices of a weight-gradient kernel) are summed
+  // in fp32 (the reference accumulates in fp32: assignments/assignment1/train/trainer.py:57-61);
+  // at the synchronising backward the sum is narrowed to the parameter dtype for the collective,
+  // or reduced as it is with reduce_fp32.
   ShardedUnit(std::vector<at::Tensor> params, std::shared_ptr<Communicator> comm, int strategy,
-              bool force_collectives, bool reduce_fp32)
+              bool force_collectives, bool reduce_fp32, bool accum_fp32)
       : params_(std::move(params)), comm_(std::move(comm)), strategy_(strategy),
-        force_collectives_(force_collectives), reduce_fp32_(reduce_fp32) {
+        force_collectives_(force_collectives), reduce_fp32_(reduce_fp32), accum_fp32_(accum_fp32) {
     TORCH_CHECK(!params_.empty(), "ShardedUnit: no parameters");
     TORCH_CHECK(strategy_ >= 0 && strategy_ <= 2, "ShardedUnit: bad strategy");
     world_ = comm_ ? comm_->world() : 1;
@@ -146,9 +151,15 @@ class ShardedUnit {
     }
     unsharded_ = true;
     if (strategy_ != kNoShard) reshard();
-    full_grad_ = make_resizable(padded_numel_, opts);
+    accum_fp32_ = accum_fp32_ && mixed_;
+    full_grad_ = make_resizable(padded_numel_, accum_fp32_ ? opts.dtype(at::kFloat) : opts);
     release_storage(full_grad_);
-    if (reduce_fp32_ && mixed_) {
+    if (accum_fp32_) {
+      if (!reduce_fp32_) {
+        narrow_grad_ = make_resizable(padded_numel_, opts);
+        release_storage(narrow_grad_);
+      }
+    } else if (reduce_fp32_ && mixed_) {
       wide_grad_ = make_resizable(padded_numel_, opts.dtype(at::kFloat));
       release_storage(wide_grad_);
     }
@@ -254,6 +265,14 @@ class ShardedUnit {
     at::Tensor mine = strategy_ == kNoShard ? padded : padded.narrow(0, shard_index_ * shard_numel_, shard_numel_);
     shard_master_.copy_(mine);
     if (mixed_) shard_lowp_.copy_(strategy_ == kNoShard ? padded : mine);
+    invalidate_unsharded();
+  }
+
+  // The shard changed behind an unsharded copy's back (a checkpoint was loaded after a forward
+  // that left the unit gathered: the root, SHARD_GRAD_OP units and resident units stay unsharded
+  // until a backward ends): drop the copy so the next forward gathers the new values.
+  void invalidate_unsharded() {
+    if (strategy_ != kNoShard && (unsharded_ || ag_issued_)) reshard();
   }
 
   // ---- accessors for the Python wrapper -------------------------------------------
@@ -269,6 +288,7 @@ class ShardedUnit {
   int64_t shard_index() const { return shard_index_; }
   int strategy() const { return strategy_; }
   bool mixed() const { return mixed_; }
+  bool accumulates_fp32() const { return accum_fp32_; }
   int64_t num_allgathers() const { return num_allgathers_; }
   int64_t num_reductions() const { return num_reductions_; }
   bool reshard_after_forward = true;  // FULL_SHARD non-root units; the wrapper clears it for the root
@@ -340,7 +360,12 @@ class ShardedUnit {
     // shard the reduced fp32 result is then the optimizer's gradient as it is.
     const bool comms = communicates();
     at::Tensor in = full_grad_;
-    if (wide_grad_.defined() && comms) {
+    if (narrow_grad_.defined() && comms) {
+      at::NoGradGuard ng;
+      allocate_storage(narrow_grad_, padded_numel_);
+      narrow_grad_.copy_(full_grad_);  // the fp32 sum of the window, rounded once
+      in = narrow_grad_;
+    } else if (wide_grad_.defined() && comms) {
       at::NoGradGuard ng;
       allocate_storage(wide_grad_, padded_numel_);
       wide_grad_.copy_(full_grad_);
@@ -376,7 +401,8 @@ class ShardedUnit {
     TORCH_CHECK(flat_param_.defined(), "ShardedUnit: flat parameter was never registered");
     at::Tensor& g = flat_param_.mutable_grad();
     const bool aliases_buffer = reduced_.storage().is_alias_of(full_grad_.storage()) ||
-                                (wide_grad_.defined() && reduced_.storage().is_alias_of(wide_grad_.storage()));
+                                (wide_grad_.defined() && reduced_.storage().is_alias_of(wide_grad_.storage())) ||
+                                (narrow_grad_.defined() && reduced_.storage().is_alias_of(narrow_grad_.storage()));
     if (!g.defined()) {
       if (reduced_.scalar_type() == flat_param_.scalar_type() && !aliases_buffer) {
         g = reduced_;
@@ -388,6 +414,7 @@ class ShardedUnit {
     }
     reduced_.reset();
     if (wide_grad_.defined()) release_storage(wide_grad_);
+    if (narrow_grad_.defined()) release_storage(narrow_grad_);
     release_storage(full_grad_);
     grad_allocated_ = false;
     std::fill(grad_written_.begin(), grad_written_.end(), false);
@@ -401,6 +428,7 @@ class ShardedUnit {
     }
     reduced_.reset();
     if (wide_grad_.defined()) release_storage(wide_grad_);
+    if (narrow_grad_.defined()) release_storage(narrow_grad_);
     if (grad_allocated_) {
       release_storage(full_grad_);
       grad_allocated_ = false;
@@ -415,12 +443,13 @@ class ShardedUnit {
   int strategy_;
   bool force_collectives_;
   bool reduce_fp32_ = false;  // reduce low-precision gradients through an fp32 copy
+  bool accum_fp32_ = false;   // keep the unsharded gradients of low-precision parameters in fp32
   int world_ = 1, rank_ = 0;
   bool mixed_ = false;
   std::vector<int64_t> offsets_;
   int64_t total_numel_ = 0, shard_numel_ = 0, padded_numel_ = 0, shard_index_ = 0;
 
-  at::Tensor shard_master_, shard_lowp_, full_param_, full_grad_, wide_grad_, flat_param_, reduced_;
+  at::Tensor shard_master_, shard_lowp_, full_param_, full_grad_, wide_grad_, narrow_grad_, flat_param_, reduced_;
   bool unsharded_ = false, ag_issued_ = false;
   std::shared_ptr<Work> ag_work_, rs_work_;
   bool grad_allocated_ = false, reduce_launched_ = false, unit_done_ = false;
@@ -496,6 +525,12 @@ class ShardedRuntime {
     // A recomputed forward inside backward must not reshard: the backward still needs the parameters.
     const bool resident = index < (int64_t)resident_.size() && resident_[index];
     if (u.strategy_ == kFullShard && u.reshard_after_forward && !resident && !in_backward()) u.reshard();
+    // End of a forward that no backward will follow (evaluation under no_grad): nothing would ever
+    // reshard the root, SHARD_GRAD_OP units and resident units, and an optimizer step or a loaded
+    // checkpoint would then go unnoticed by the next forward. Release them now.
+    if (index == 0 && !torch::autograd::GradMode::is_enabled() && !in_backward())
+      for (auto& other : units_)
+        if (other->strategy_ != kNoShard) other->reshard();
   }
 
   // Chooses the units that stay unsharded between forward and backward: the longest suffix of
@@ -638,9 +673,10 @@ void ShardedUnit::on_grad_ready(size_t i) {
 
 void bind_fsdp(py::module_& m) {
   py::class_<ShardedUnit, std::shared_ptr<ShardedUnit>>(m, "ShardedUnit")
-      .def(py::init<std::vector<at::Tensor>, std::shared_ptr<Communicator>, int, bool, bool>(), py::arg("params"),
+      .def(py::init<std::vector<at::Tensor>, std::shared_ptr<Communicator>, int, bool, bool, bool>(), py::arg("params"),
            py::arg("communicator"), py::arg("strategy"), py::arg("force_collectives") = false,
-           py::arg("reduce_fp32") = false)
+           py::arg("reduce_fp32") = false, py::arg("accum_fp32") = false)
+      .def("accumulates_fp32", &ShardedUnit::accumulates_fp32)
       .def("unshard", &ShardedUnit::unshard)
       .def("wait_unshard", &ShardedUnit::wait_unshard)
       .def("reshard", &ShardedUnit::reshard)
@@ -649,6 +685,7 @@ void bind_fsdp(py::module_& m) {
       .def("refresh_shard_from_full", &ShardedUnit::refresh_shard_from_full)
       .def("gather_shards", &ShardedUnit::gather_shards, py::arg("shard"), py::call_guard<py::gil_scoped_release>())
       .def("load_master_from_full", &ShardedUnit::load_master_from_full, py::arg("full"))
+      .def("invalidate_unsharded", &ShardedUnit::invalidate_unsharded)
       .def("remove_hooks", &ShardedUnit::remove_hooks)
       .def("shard_master", &ShardedUnit::shard_master)
       .def("shard_lowp", &ShardedUnit::shard_lowp)

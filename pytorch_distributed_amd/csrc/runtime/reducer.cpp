@@ -14,6 +14,16 @@
 //     for all outstanding collectives (an event wait, never a host synchronisation on
 //     the GPU backend).
 //   * no_sync: hooks keep accumulating into the bucket views, nothing is launched.
+//   * fp32 gradient accumulation (`accum_fp32`, for low-precision parameters): every bucket gets
+//     an fp32 twin. Weight-gradient kernels write / add their fp32 results straight into the twin
+//     (grad_slot: the parameter's gradient sink); any gradient autograd itself delivers is added
+//     to the twin by the hook and .grad is dropped again, so the micro-batches of an accumulation
+//     window are summed in fp32 — what the reference's fp32 training does
+//     (assignments/assignment1/train/trainer.py:57-61) — instead of being rounded to bf16 after
+//     every addition. At the synchronising backward the twin is narrowed into the bucket and the
+//     bucket is reduced (or, with `reduce_fp32`, the twin itself is reduced and narrowed after),
+//     and .grad becomes the bucket view for the optimizer; it is dropped again at the next forward
+//     (the twin, not .grad, carries gradient state from one micro-batch to the next).
 //
 // Collectives go through pda::comm::Communicator (RCCL on the communicator's own HIP streams
 // on GPUs, the TCP mesh on CPUs), so the same reducer is exercised by the CPU tests.
@@ -66,15 +76,16 @@ struct Bucket {
   bool launched = false;
   at::Tensor wide;               // persistent fp32 copy that is reduced instead of `flat` (fp32-reduction option)
   bool wide_in_flight = false;
+  at::Tensor accum;              // fp32 accumulation twin (accum_fp32 and a low-precision bucket)
   std::vector<std::shared_ptr<Work>> work;
 };
 
 class GradReducer {
  public:
   GradReducer(std::vector<at::Tensor> params, std::shared_ptr<Communicator> comm, int64_t bucket_cap_bytes,
-              int64_t first_bucket_bytes, bool force_collectives, bool reduce_fp32, bool decompose)
+              int64_t first_bucket_bytes, bool force_collectives, bool reduce_fp32, bool decompose, bool accum_fp32)
       : params_(std::move(params)), comm_(std::move(comm)), force_collectives_(force_collectives),
-        reduce_fp32_(reduce_fp32), decompose_(decompose) {
+        reduce_fp32_(reduce_fp32), decompose_(decompose), accum_fp32_(accum_fp32) {
     TORCH_CHECK(!params_.empty(), "GradReducer: no parameters");
     TORCH_CHECK(bucket_cap_bytes > 0 && first_bucket_bytes > 0, "GradReducer: bucket sizes must be positive");
     world_ = comm_ ? comm_->world() : 1;
@@ -102,7 +113,30 @@ class GradReducer {
   }
 
   void zero_grad() {
+    std::lock_guard<std::mutex> lock(mu_);
     for (auto& b : buckets_) b.flat.zero_();
+    std::fill(accum_dirty_.begin(), accum_dirty_.end(), false);  // the twins restart by overwriting
+  }
+
+  // Gradient sink of parameter `idx` under fp32 accumulation: the fp32 slice its gradient kernel
+  // should write (second element false: first contribution of the window) or add to (true). The
+  // accumulator hook still fires afterwards and counts the parameter as ready.
+  std::pair<at::Tensor, bool> grad_slot(size_t idx) {
+    TORCH_CHECK(idx < params_.size(), "GradReducer: bad parameter index");
+    std::lock_guard<std::mutex> lock(mu_);
+    Bucket& b = buckets_[param_bucket_[idx].first];
+    TORCH_CHECK(b.accum.defined(), "GradReducer: parameter ", idx, " has no fp32 accumulation buffer");
+    const bool accumulate = accum_dirty_[idx];
+    accum_dirty_[idx] = true;
+    return {accum_view(idx), accumulate};
+  }
+  bool accumulates_fp32(size_t idx) const {
+    return idx < params_.size() && buckets_[param_bucket_[idx].first].accum.defined();
+  }
+  std::vector<at::Tensor> accum_tensors() const {
+    std::vector<at::Tensor> out;
+    for (auto& b : buckets_) out.push_back(b.accum.defined() ? b.accum : at::Tensor());
+    return out;
   }
 
   // Called at the start of every wrapper forward. A backward that raised never ran its
@@ -110,6 +144,17 @@ class GradReducer {
   // its set-up (no bucket launched, optimizer stepping on unsynchronised gradients): close it.
   void prepare_forward() {
     std::lock_guard<std::mutex> lock(mu_);
+    if (accum_fp32_) {
+      // fp32 accumulation: between backward passes the twins hold the gradients; a .grad left from
+      // the last synchronising pass (the optimizer has consumed it) must not be added to again.
+      for (auto& b : buckets_) {
+        if (!b.accum.defined()) continue;
+        for (size_t idx : b.params) {
+          at::Tensor& g = params_[idx].mutable_grad();
+          if (g.defined()) g.reset();
+        }
+      }
+    }
     if (!in_pass_) return;
     for (auto& b : buckets_) {
       for (auto& w : b.work) w->wait();
@@ -154,6 +199,8 @@ class GradReducer {
       // The two-phase reduction needs world equal chunks; pad the bucket (never a parameter).
       const int64_t total = decompose_ ? align_up(cur_elems, kAlignElems * world_) : cur_elems;
       b.flat = at::zeros({total}, p0.options().requires_grad(false));
+      if (accum_fp32_ && p0.scalar_type() != at::kFloat && p0.scalar_type() != at::kDouble)
+        b.accum = at::zeros({total}, p0.options().requires_grad(false).dtype(at::kFloat));
       int64_t off = 0;
       for (size_t idx : cur) {
         b.params.push_back(idx);
@@ -180,6 +227,7 @@ class GradReducer {
       cur_elems += need;
     }
     flush();
+    accum_dirty_.assign(params_.size(), false);
     // Point every .grad at its bucket slice (preserving an existing gradient's value).
     for (size_t i = 0; i < params_.size(); ++i) bind_grad_view(i, /*copy_existing=*/true);
   }
@@ -189,6 +237,41 @@ class GradReducer {
     const at::Tensor& p = params_[idx];
     return buckets_[b].flat.narrow(0, buckets_[b].offsets[slot], p.numel()).view(p.sizes());
   }
+
+  at::Tensor accum_view(size_t idx) const {
+    const auto [b, slot] = param_bucket_[idx];
+    const at::Tensor& p = params_[idx];
+    return buckets_[b].accum.narrow(0, buckets_[b].offsets[slot], p.numel()).view(p.sizes());
+  }
+
+  // fp32 accumulation: a gradient autograd delivered this micro-batch (.grad is defined: it was
+  // dropped after the previous one) is added to the fp32 twin and dropped again. A gradient whose
+  // kernel wrote the twin directly (grad_slot) never shows up in .grad.
+  void fold_into_accum(size_t idx) {
+    at::Tensor& g = params_[idx].mutable_grad();
+    if (!g.defined()) return;
+    at::NoGradGuard ng;
+    at::Tensor acc = accum_view(idx);
+    if (accum_dirty_[idx]) acc.add_(g);
+    else acc.copy_(g);
+    accum_dirty_[idx] = true;
+    g.reset();
+  }
+
+  // Synchronising backward: the twin's sum becomes the bucket's content (parameters that received
+  // nothing in the whole window contribute zeros).
+  void settle_accum(Bucket& b) {
+    at::NoGradGuard ng;
+    for (size_t k = 0; k < b.params.size(); ++k) {
+      const size_t idx = b.params[k];
+      if (!accum_dirty_[idx]) accum_view(idx).zero_();
+      accum_dirty_[idx] = false;
+    }
+    if (!(reduce_fp32_ && communicates())) b.flat.copy_(b.accum);
+    for (size_t idx : b.params) bind_grad_view(idx, /*copy_existing=*/false);  // what the optimizer reads
+  }
+
+  bool communicates() const { return comm_ && (world_ > 1 || force_collectives_); }
 
   void bind_grad_view(size_t idx, bool copy_existing) {
     at::Tensor& p = params_[idx];
@@ -232,9 +315,11 @@ class GradReducer {
 
   void on_grad_ready(size_t idx) {
     std::lock_guard<std::mutex> lock(mu_);
+    const bool twin = buckets_[param_bucket_[idx].first].accum.defined();
+    if (twin) fold_into_accum(idx);
     // If something replaced .grad (e.g. zero_grad(set_to_none=True) followed by a fresh
     // gradient tensor), fold it back into the bucket so the view invariant holds again.
-    {
+    if (!twin) {
       const at::Tensor& g = params_[idx].grad();
       at::Tensor view = grad_view(idx);
       if (g.defined() && g.data_ptr() != view.data_ptr()) {
@@ -264,13 +349,18 @@ class GradReducer {
 
   void launch(Bucket& b) {
     b.launched = true;
-    if (!comm_ || (world_ == 1 && !force_collectives_)) return;
+    if (b.accum.defined()) settle_accum(b);
+    if (!communicates()) return;
     pda::trace::Scope range("bucket reduction launch", "comm");
     // fp32 reduction of low-precision gradients: the bucket is widened into a persistent fp32
     // twin, the twin is reduced (twice the bytes on the wire, no rounding between the ranks'
     // contributions) and narrowed back into the bucket when the pass finishes.
     at::Tensor payload = b.flat;
-    if (reduce_fp32_ && b.flat.scalar_type() != at::kFloat) {
+    if (reduce_fp32_ && b.accum.defined()) {
+      b.wide = b.accum;  // the fp32 sum is reduced as it is and narrowed into the bucket afterwards
+      b.wide_in_flight = true;
+      payload = b.wide;
+    } else if (reduce_fp32_ && b.flat.scalar_type() != at::kFloat) {
       at::NoGradGuard ng;
       if (!b.wide.defined()) b.wide = at::empty(b.flat.sizes(), b.flat.options().dtype(at::kFloat));
       b.wide.copy_(b.flat);
@@ -318,6 +408,8 @@ class GradReducer {
   bool force_collectives_ = false;
   bool reduce_fp32_ = false;
   bool decompose_ = false;
+  bool accum_fp32_ = false;
+  std::vector<bool> accum_dirty_;  // per parameter: its slice of the twin was written in this window
   bool require_sync_ = true;
   bool in_pass_ = false;
   size_t next_bucket_ = 0;
@@ -336,9 +428,13 @@ class GradReducer {
 
 void bind_reducer(py::module_& m) {
   py::class_<GradReducer, std::shared_ptr<GradReducer>>(m, "GradReducer")
-      .def(py::init<std::vector<at::Tensor>, std::shared_ptr<Communicator>, int64_t, int64_t, bool, bool, bool>(),
+      .def(py::init<std::vector<at::Tensor>, std::shared_ptr<Communicator>, int64_t, int64_t, bool, bool, bool, bool>(),
            py::arg("params"), py::arg("communicator"), py::arg("bucket_cap_bytes"), py::arg("first_bucket_bytes"),
-           py::arg("force_collectives") = false, py::arg("reduce_fp32") = false, py::arg("decompose") = false)
+           py::arg("force_collectives") = false, py::arg("reduce_fp32") = false, py::arg("decompose") = false,
+           py::arg("accum_fp32") = false)
+      .def("grad_slot", &GradReducer::grad_slot, py::arg("index"))
+      .def("accumulates_fp32", &GradReducer::accumulates_fp32, py::arg("index"))
+      .def("accum_tensors", &GradReducer::accum_tensors)
       .def("set_sync", &GradReducer::set_sync)
       .def("sync_enabled", &GradReducer::sync_enabled)
       .def("remove_hooks", &GradReducer::remove_hooks)

@@ -27,7 +27,12 @@ from .. import _ext
 
 def _grad_target(param, sink):
     """Where a parameter's gradient should be written: ``(tensor, accumulate)`` from the owner's sink,
-    else an existing contiguous ``.grad`` (accumulate), else None (fresh tensor handed to autograd)."""
+    else an existing contiguous ``.grad`` (accumulate), else None (fresh tensor handed to autograd).
+    The embedding kernels write the parameter's own dtype only: a wider sink (fp32 accumulation of a
+    bf16 table) is left alone and the owner's hook adds the returned gradient itself."""
+    wide = getattr(param, "_pda_grad_sink_dtype", None)
+    if wide is not None and wide != param.dtype:
+        sink = None
     target = sink() if sink is not None else None
     if target is None and param.grad is not None and param.grad.is_contiguous():
         target = (param.grad, True)

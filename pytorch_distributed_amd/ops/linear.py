@@ -131,11 +131,22 @@ def input_grad_mm(dy2: torch.Tensor, weight: torch.Tensor, dy_padded: torch.Tens
     return routes[int(choice)]()
 
 
-def _grad_target(param, sink):
+def sink_is_wide(param) -> bool:
+    """True when the owner's gradient sink hands out a buffer of another dtype than the parameter's
+    (fp32 gradient accumulation of a bf16 parameter)."""
+    wide = getattr(param, "_pda_grad_sink_dtype", None)
+    return wide is not None and wide != param.dtype
+
+
+def _grad_target(param, sink, wide_ok: bool = True):
     """Where a parameter's gradient kernel should write: ``(tensor, accumulate)`` from the owner's
-    sink, else the existing contiguous ``.grad`` (accumulate), else None (fresh tensor to autograd)."""
+    sink, else the existing contiguous ``.grad`` (accumulate), else None (fresh tensor to autograd).
+    ``wide_ok=False``: the caller's kernel can only write the parameter's own dtype, so a wider
+    sink is left alone (the owner's accumulator hook then adds the returned gradient itself)."""
     if param is None:
         return None
+    if sink is not None and not wide_ok and sink_is_wide(param):
+        sink = None
     target = sink() if sink is not None else None
     if target is None and param.grad is not None and param.grad.is_contiguous():
         target = (param.grad, True)

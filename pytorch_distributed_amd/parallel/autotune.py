@@ -18,6 +18,13 @@ part of that curve. So the policy is measured, not assumed:
    * the FSDP unit size the same way on the all-gather curve, converted to whole transformer
      blocks per unit and capped so >= ``min_units`` units remain for prefetch overlap.
 
+4. ``measure_gather_behind_reduce()`` — when the RCCL communicator owns a second library
+   communicator for its all-gather queue — times the pattern of a sharded backward: a large
+   reduce-scatter is issued, then the (small) all-gather prefetch of the next unit. On ONE library
+   communicator the gather runs after the reduction; on two they run concurrently and share the
+   links. Whichever finishes the GATHER sooner without slowing the pair down is kept
+   (``policy.dual_route``), and the communicator is switched accordingly.
+
 Explicit flags (``--bucket-mb``, ``--fsdp-unit-blocks``, ``--ddp-decompose``) always override;
 the chosen values are logged by rank 0 at start-up.
 
@@ -48,6 +55,8 @@ class CommPolicy:
     ddp_bucket_mb: float = 64.0
     ddp_decompose: bool = False
     fsdp_unit_mb: float = 64.0          # target unsharded bytes of one unit (bf16 parameters)
+    dual_route: Optional[bool] = None   # all-gathers on a second library communicator (None: there is none)
+    gather_behind_reduce_us: Dict[str, Tuple[float, float]] = dataclasses.field(default_factory=dict)
     source: str = "default"             # "default" | "measured" | "model"
     fits: Dict[str, Tuple[float, float]] = dataclasses.field(default_factory=dict)  # kind -> (latency s, bytes/s)
     measurements: Dict[str, List[Tuple[int, float]]] = dataclasses.field(default_factory=dict)
@@ -66,6 +75,9 @@ class CommPolicy:
                  f"fsdp_unit_mb={self.fsdp_unit_mb:g}", f"source={self.source}"]
         for kind, (a, b) in sorted(self.fits.items()):
             parts.append(f"{kind}: {a * 1e6:.0f}us + S/{b / 1e9:.0f}GB/s")
+        if self.dual_route is not None:
+            parts.append(f"dual_route={self.dual_route} " + " ".join(
+                f"{k}: gather {g:.0f}us / pair {p:.0f}us" for k, (g, p) in sorted(self.gather_behind_reduce_us.items())))
         return ", ".join(parts)
 
 
@@ -200,6 +212,52 @@ def measure(communicator, device, ladder_mb: Sequence[float] = DEFAULT_LADDER_MB
     return out
 
 
+def measure_gather_behind_reduce(communicator, device, reduce_mb: float = 64.0, gather_mb: float = 16.0,
+                                 iters: int = 4, dtype=torch.bfloat16) -> Dict[str, Tuple[float, float]]:
+    """For a communicator with a second library communicator: ``{"shared" | "dual": (microseconds
+    until the all-gather issued right behind a reduce-scatter has completed, microseconds until both
+    have)}``, slowest rank. Collective; leaves the route as it found it."""
+    world = communicator.world_size
+    es = torch.empty((), dtype=dtype).element_size()
+
+    def sized(mb):
+        n = int(mb * MB) // es
+        return max(world * 64, n // (world * 64) * (world * 64))
+
+    big = torch.zeros(sized(reduce_mb), dtype=dtype, device=device)
+    big_mine = big.narrow(0, communicator.rank * (big.numel() // world), big.numel() // world)
+    small = torch.zeros(sized(gather_mb), dtype=dtype, device=device)
+    small_mine = small.narrow(0, communicator.rank * (small.numel() // world), small.numel() // world)
+    was = communicator.dual_route()
+    out = {}
+    try:
+        for name, route in (("shared", False), ("dual", True)):
+            communicator.set_dual_route(route)
+            t_gather = t_pair = 0.0
+            for it in range(iters + 1):  # first round warms the route up
+                torch.cuda.synchronize(device)
+                communicator.barrier()
+                t0 = time.perf_counter()
+                rs = communicator.reduce_scatter(big_mine, big, "avg", 1)
+                ag = communicator.all_gather(small, small_mine, 0)
+                ag.synchronize()
+                t1 = time.perf_counter()
+                rs.synchronize()
+                t2 = time.perf_counter()
+                if it:
+                    t_gather += (t1 - t0) / iters
+                    t_pair += (max(t1, t2) - t0) / iters
+            t = torch.tensor([t_gather, t_pair], dtype=torch.float64, device=device)
+            if world > 1:
+                communicator.all_reduce(t, "max", 1).wait()
+                torch.cuda.synchronize(device)
+            g, p = t.cpu().tolist()
+            out[name] = (g * 1e6, p * 1e6)
+    finally:
+        communicator.set_dual_route(was)
+    return out
+
+
 def rccl_environment() -> Dict[str, str]:
     """Every RCCL / NCCL tuning variable visible to this process (logged with the policy)."""
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}
@@ -218,6 +276,17 @@ def tune(communicator=None, device=None, total_grad_bytes: int = 0, verbose: boo
         return policy
     device = device if device is not None else comm.comm_device()
     policy = choose_policy(measure(c, device, ladder_mb), total_grad_bytes)
+    if getattr(c, "has_dual", None) is not None and c.has_dual():
+        try:
+            policy.gather_behind_reduce_us = measure_gather_behind_reduce(c, device)
+            (g_s, p_s), (g_d, p_d) = policy.gather_behind_reduce_us["shared"], policy.gather_behind_reduce_us["dual"]
+            policy.dual_route = bool(g_d < 0.9 * g_s and p_d < 1.05 * p_s)
+        except Exception as exc:  # noqa: BLE001 - the shared route always works
+            if c.rank == 0:
+                print(f"[pda.comm] gather-behind-reduce measurement failed ({exc!r}); gathers stay on the shared "
+                      "communicator")
+            policy.dual_route = False
+        c.set_dual_route(policy.dual_route)
     set_policy(policy)
     if verbose and c.rank == 0:
         print(f"[pda.comm] policy: {policy.describe()}")

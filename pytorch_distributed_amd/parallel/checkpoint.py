@@ -256,6 +256,7 @@ def _restore_unit(u, shard: torch.Tensor, optim: Optional[dict], optimizer) -> N
                 lowp.copy_(u.flat_param)
             else:  # NO_SHARD: the mirror is the whole live buffer
                 lowp.view(-1)[: u.flat_param.numel()].copy_(u.flat_param)
+    u.unit.invalidate_unsharded()  # a gathered copy from an earlier forward holds the old values
     if optimizer is not None and optim is not None:
         st = optimizer.state[u.flat_param]
         st["step"] = torch.tensor(optim["step"], dtype=torch.float32)

@@ -25,6 +25,8 @@ from __future__ import annotations
 import datetime
 import os
 import struct
+import subprocess
+import sys
 from typing import List, Optional, Tuple
 
 import torch
@@ -34,6 +36,45 @@ from .. import _ext
 _COMM = None          # the process-wide communicator
 _DEVICE = None
 _OWNS_C10D = False
+RELAUNCH_STDOUT_FD: Optional[int] = None  # where a relaunched child's stdout goes (a script that redirected fd 1 sets it)
+
+
+def prepare_multiprocess_env(environ=None) -> None:
+    """Environment a multi-rank GPU job needs, set BEFORE anything initialises the HIP runtime.
+
+    RCCL's intra-node transport shares device memory between the ranks; on hosts whose driver only
+    offers dmabuf IPC that needs ``HSA_ENABLE_IPC_MODE_LEGACY=0``, read once when the runtime starts.
+    Only a job with more than one rank gets the default, an explicit setting always wins, and
+    nothing happens on import of the package: the launchers (``bench.py``, the train scripts) call
+    this first thing."""
+    env = os.environ if environ is None else environ
+    if int(env.get("WORLD_SIZE", "1")) > 1:
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+class NativeCommunicatorStuck(RuntimeError):
+    """The native communicator's start-up neither finished nor failed within its time limit on this
+    rank: its helper thread is still inside the collective library, so nothing else may initialise
+    that library in this process."""
+
+
+def relaunch_self_on_c10d() -> "NoReturn":  # noqa: F821
+    """Runs this very command again as a CHILD process on the torch.distributed backend and exits
+    with its code. Used when the native communicator's start-up is stuck inside the collective
+    library (a thread that cannot be cancelled): a fresh process is the only clean state. The child
+    inherits the launcher's environment (rank, world size, rendezvous address) and joins the other
+    ranks — relaunched or fallen back in-process alike — through torch.distributed's own store."""
+    env = dict(os.environ)
+    env["PDA_COMM_BACKEND"] = "c10d"
+    env["PDA_COMM_RELAUNCHED"] = "1"
+    kw = {}
+    if RELAUNCH_STDOUT_FD is not None:
+        kw["stdout"] = RELAUNCH_STDOUT_FD
+    print(f"[comm] rank {env_rank_world()[0]}: relaunching on the torch.distributed backend", flush=True)
+    code = subprocess.call([sys.executable, *sys.argv], env=env, **kw)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)  # not sys.exit: the stuck helper thread must not be joined by interpreter shutdown
 
 
 def env_rank_world() -> Tuple[int, int, int]:
@@ -80,7 +121,9 @@ def _self_test(comm, device: torch.device) -> None:
 def _verified_native(create, device, probe_timeout_s: float):
     """Builds the native communicator in a helper thread, self-tests it, and lets the ranks vote
     (through the rendezvous store, which does not depend on the collective library). Returns the
-    communicator, or None when any rank failed or timed out."""
+    communicator, or None when some rank failed and THIS rank's helper thread has ended (an
+    in-process fallback is then safe). Raises :class:`NativeCommunicatorStuck` when the helper is
+    still running — inside ``ncclCommInitRank`` or a collective that never returns."""
     import threading
 
     box = {}
@@ -98,7 +141,7 @@ def _verified_native(create, device, probe_timeout_s: float):
     t = threading.Thread(target=work, daemon=True)
     t.start()
     t.join(probe_timeout_s)
-    mine_ok = bool(box.get("ok"))
+    mine_ok = bool(box.get("ok")) and not t.is_alive()
     if not mine_ok:
         print(f"[comm] native communicator unusable on rank {env_rank_world()[0]}: "
               f"{box.get('error', f'no answer within {probe_timeout_s:.0f} s')}", flush=True)
@@ -106,6 +149,8 @@ def _verified_native(create, device, probe_timeout_s: float):
     all_ok = False
     if comm is not None:
         try:
+            # exchange() only talks to the rendezvous store (its sequence number is atomic), so it is
+            # safe beside a helper thread that is still inside a collective
             all_ok = all(v == b"1" for v in comm.exchange(b"1" if mine_ok else b"0"))
         except Exception as exc:  # noqa: BLE001 - a peer never built its communicator
             print(f"[comm] vote failed on rank {env_rank_world()[0]}: {exc!r}", flush=True)
@@ -113,15 +158,24 @@ def _verified_native(create, device, probe_timeout_s: float):
         return comm
     if comm is not None:
         try:
-            comm.abort()  # a collective the helper thread is still blocked in raises now
+            comm.abort()  # a collective the helper thread is still blocked in ends now
         except Exception:  # noqa: BLE001
             pass
     t.join(20)  # let the helper unwind before anything else happens on this process
+    if t.is_alive():
+        raise NativeCommunicatorStuck(
+            f"rank {env_rank_world()[0]}: the native communicator's start-up is still running after "
+            f"{probe_timeout_s + 20:.0f} s and cannot be cancelled")
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:  # noqa: BLE001
+            pass
     return None
 
 
 def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fallback: Optional[str] = None,
-                     probe_timeout_s: float = 150.0) -> Tuple[int, int, torch.device]:
+                     probe_timeout_s: float = 150.0, dual: Optional[bool] = None) -> Tuple[int, int, torch.device]:
     """Creates the process-wide communicator from the torchrun environment.
 
     ``backend``: ``"rccl"`` (alias ``"nccl"``), ``"socket"`` (alias ``"gloo"``: the CPU backend),
@@ -130,6 +184,12 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
     under ``probe_timeout_s``, the ranks vote, and unless every rank passed, all of them switch to a
     ``torch.distributed`` group behind the same interface — a job then still runs (and says so:
     ``get_communicator().backend`` starts with ``c10d:``) on a machine where the native path fails.
+    A rank whose native start-up is STUCK inside the collective library (neither done nor failed)
+    cannot fall back in-process; it runs the same command again as a child process on ``c10d`` and
+    exits with the child's code (:func:`relaunch_self_on_c10d`).
+    ``dual``: the RCCL communicator gets a second library communicator for the all-gather queue, so
+    gathers and reductions run concurrently (None = ``PDA_COMM_DUAL=1``; the start-up autotuner
+    decides whether gathers are routed to it: ``autotune.tune``).
     Returns ``(rank, world_size, device)``. Safe to call when already initialised.
     """
     global _COMM, _DEVICE, _OWNS_C10D
@@ -137,8 +197,12 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
     if _COMM is not None:
         return _COMM.rank, _COMM.world_size, _DEVICE
     backend = {"nccl": "rccl", "gloo": "socket", None: None}.get(backend, backend)
+    if os.environ.get("PDA_COMM_RELAUNCHED") == "1":
+        backend = os.environ.get("PDA_COMM_BACKEND", "c10d")  # this process IS the fallback of a stuck start-up
     if backend is None:
         backend = os.environ.get("PDA_COMM_BACKEND") or ("rccl" if torch.cuda.is_available() else "socket")
+    if dual is None:
+        dual = os.environ.get("PDA_COMM_DUAL", "0") == "1"
     if fallback not in (None, "c10d"):
         raise ValueError("fallback must be None or 'c10d'")
     ext = _ext.require()
@@ -151,9 +215,13 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
         torch.cuda.set_device(device)
         torch.zeros(1, device=device)  # the HIP context exists before RCCL initialises
         create = lambda: ext.create_communicator("rccl", rank, world, host, _store_port(), local_rank,  # noqa: E731
-                                                 timeout_s, job)
+                                                 timeout_s, job, bool(dual))
         if fallback == "c10d":
-            _COMM = _verified_native(create, device, probe_timeout_s)
+            try:
+                _COMM = _verified_native(create, device, probe_timeout_s)
+            except NativeCommunicatorStuck as exc:
+                print(f"[comm] {exc}", flush=True)
+                relaunch_self_on_c10d()
             if _COMM is None:
                 backend = "c10d"
         else:
@@ -162,7 +230,11 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
         device = torch.device("cpu")
         create = lambda: ext.create_communicator("socket", rank, world, host, _store_port(), 0, timeout_s, job)  # noqa: E731
         if fallback == "c10d":
-            _COMM = _verified_native(create, device, probe_timeout_s)
+            try:
+                _COMM = _verified_native(create, device, probe_timeout_s)
+            except NativeCommunicatorStuck as exc:
+                print(f"[comm] {exc}", flush=True)
+                relaunch_self_on_c10d()
             if _COMM is None:
                 backend = "c10d"
         else:
@@ -191,6 +263,8 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
     _DEVICE = device
     if rank == 0:
         extra = f", RCCL {_COMM.rccl_version()}" if backend == "rccl" else ""
+        if backend == "rccl" and _COMM.has_dual():
+            extra += ", second library communicator for the gather queue"
         print(f"Initialized process group: world_size={world}, backend={_COMM.backend}{extra}")
     return rank, world, device
 
@@ -328,21 +402,62 @@ def broadcast_coalesced(tensors: List[torch.Tensor], root: int = 0, communicator
             flush(batch)
 
 
+_SCALAR_STREAMS = {}
+
+
+def _scalar_stream(device: torch.device):
+    """A side stream per device for the read-back of logged scalars."""
+    st = _SCALAR_STREAMS.get(device)
+    if st is None:
+        st = _SCALAR_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 class LazyScalarMean:
-    """Mean of a device scalar over all ranks, issued now on the reduction queue and read later.
+    """Mean of a device scalar over all ranks, issued now and read later.
 
     The logging all-reduce of the reference (assignments/assignment1/train/distributed_trainer.py:131-154)
-    blocks every rank on a 4-byte collective; here it rides the side stream and the host only
-    waits when the value is printed."""
+    blocks every rank on a 4-byte collective plus a ``.item()`` that drains the compute stream. Here
+    the collective rides the communicator's reduction queue, the result is copied into pinned host
+    memory on a side stream, and :meth:`value` waits for THAT copy only — called a step later (the
+    trainers print step k's line when step k + 1 has been enqueued) it returns at once and the
+    compute stream is never drained. Without a communicator (one process) it is the same deferred
+    read-back of the local value."""
 
-    def __init__(self, value: torch.Tensor, communicator=None):
+    def __init__(self, value: torch.Tensor, communicator=None, reduce: bool = True):
         c = communicator if communicator is not None else _COMM
         self._t = value.detach().reshape(1).to(torch.float32).clone()
         self._work = None
-        if c is not None and c.world_size > 1:
+        self._event = None
+        self._host = None
+        if reduce and c is not None and c.world_size > 1:
             self._work = c.all_reduce(self._t, "avg", 1)
+        if self._t.is_cuda:
+            dev = self._t.device
+            side, cur = _scalar_stream(dev), torch.cuda.current_stream(dev)
+            self._host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)          # the value itself
+                if self._work is not None:
+                    self._work.wait()           # the side stream waits for the collective, nobody else does
+                    self._work = None
+                self._host.copy_(self._t, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record(side)
+            self._t.record_stream(side)
+
+    def ready(self) -> bool:
+        """True when :meth:`value` would not block."""
+        if self._event is not None:
+            return self._event.query()
+        return self._work is None or self._work.completed()
 
     def value(self) -> float:
+        if self._event is not None:
+            self._event.synchronize()
+            return float(self._host[0])
         if self._work is not None:
             self._work.wait()
             self._work = None

@@ -42,11 +42,16 @@ class DDP(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, process_group=None,
                  bucket_cap_mb: Optional[float] = None, first_bucket_mb: float = DEFAULT_FIRST_BUCKET_MB,
                  broadcast_parameters: bool = True, force_collectives: bool = False, reduce_fp32: bool = False,
-                 decompose: Optional[bool] = None, communicator=None):
+                 decompose: Optional[bool] = None, communicator=None, grad_accum_dtype: Optional[str] = None):
         """``reduce_fp32``: all-reduce bf16 gradient buckets through an fp32 copy (twice the bytes on
         the wire, no rounding between the ranks' contributions); default: the gradient dtype.
         ``decompose``: reduce each bucket as reduce-scatter + all-gather instead of one all-reduce.
-        ``process_group``: a torch.distributed group to run on instead of the native communicator."""
+        ``process_group``: a torch.distributed group to run on instead of the native communicator.
+        ``grad_accum_dtype="fp32"``: low-precision (bf16) gradients are summed over the micro-batches
+        of a ``no_sync`` window in fp32 twins of the buckets instead of being rounded to bf16 after
+        every addition (the reference accumulates in fp32: assignments/assignment1/train/trainer.py:57-61);
+        the sum is narrowed (or, with ``reduce_fp32``, reduced as fp32 and then narrowed) at the
+        synchronising backward. ``.grad`` then only exists from that backward to the next forward."""
         super().__init__()
         self.module = module
         self.communicator = comm.resolve(communicator, process_group)
@@ -79,14 +84,22 @@ class DDP(nn.Module):
             comm.broadcast_coalesced(tensors, 0, self.communicator)
 
         ext = _ext.require()
+        if grad_accum_dtype not in (None, "param", "fp32"):
+            raise ValueError("grad_accum_dtype must be None / 'param' or 'fp32'")
+        self.grad_accum_dtype = "fp32" if grad_accum_dtype == "fp32" else "param"
         self.reducer = ext.GradReducer(params, self.communicator, int(bucket_cap_mb * 2**20),
-                                       int(first_bucket_mb * 2**20), force_collectives, reduce_fp32, self.decompose)
-        for p in params:
+                                       int(first_bucket_mb * 2**20), force_collectives, reduce_fp32, self.decompose,
+                                       self.grad_accum_dtype == "fp32")
+        for i, p in enumerate(params):
             p._pda_grad_is_view = True  # optimizers must zero these in place, never drop them
             # ops.linear / ops.norm add their parameter gradients straight into the bucket view
             # instead of materialising them for autograd to add (the hook on the accumulator
-            # still fires).
-            p._pda_grad_sink = functools.partial(_bucket_slot, p)
+            # still fires); under fp32 accumulation the target is the bucket's fp32 twin.
+            if self.reducer.accumulates_fp32(i):
+                p._pda_grad_sink = functools.partial(self.reducer.grad_slot, i)
+                p._pda_grad_sink_dtype = torch.float32
+            else:
+                p._pda_grad_sink = functools.partial(_bucket_slot, p)
 
     # -- module surface ----------------------------------------------------------------
     def forward(self, *args, **kwargs):

@@ -59,10 +59,14 @@ class FSDP(nn.Module):
     def __init__(self, module: nn.Module, sharding_strategy=ShardingStrategy.FULL_SHARD,
                  process_group=None, forward_prefetch: int = 1, backward_prefetch: int = 1,
                  force_collectives: bool = False, reduce_fp32: bool = False, communicator=None,
-                 resident_gb=0.0):
+                 resident_gb=0.0, grad_accum_dtype: Optional[str] = None):
         """``reduce_fp32``: reduce bf16 gradients through an fp32 copy (twice the bytes on the wire,
         no rounding between the ranks' contributions); the default reduces in the gradient dtype.
         ``process_group``: a torch.distributed group to run on instead of the native communicator.
+        ``grad_accum_dtype="fp32"``: the unit's unsharded gradient buffer is fp32 for bf16 parameters,
+        so the micro-batches of a ``no_sync`` window are summed in fp32 (the reference accumulates in
+        fp32: assignments/assignment1/train/trainer.py:57-61) and rounded once, for the collective
+        (or not at all with ``reduce_fp32``); the default keeps the parameter dtype.
         ``resident_gb`` (read from the root instance; FULL_SHARD only): GiB of unsharded parameters
         that may stay allocated between forward and backward. The last units of the model — the
         first ones backward visits — keep their parameters while they fit and are then not
@@ -102,13 +106,17 @@ class FSDP(nn.Module):
         comm.assert_same_across_ranks([p.numel() for p in mine], "FSDP unit parameter sizes", self.communicator)
 
         ext = _ext.require()
+        if grad_accum_dtype not in (None, "param", "fp32"):
+            raise ValueError("grad_accum_dtype must be None / 'param' or 'fp32'")
         self.unit = ext.ShardedUnit(mine, self.communicator, self.sharding_strategy.value, force_collectives,
-                                    reduce_fp32)
+                                    reduce_fp32, grad_accum_dtype == "fp32")
         # Weight matrices hand ops.linear a slice of this unit's flat gradient buffer, so the
         # weight-gradient kernel writes there directly instead of producing a tensor that the
         # gradient hook then copies (one copy kernel per parameter and micro-batch).
         for i, p in enumerate(mine):
             p._pda_grad_sink = functools.partial(self.unit.grad_slot, i)
+            if self.unit.accumulates_fp32():
+                p._pda_grad_sink_dtype = torch.float32
         # The flat shard is deliberately NOT registered as a module parameter (plain attribute,
         # bypassing nn.Module.__setattr__): state_dict() keeps the original names, .to() never
         # touches it, and parameters() is overridden below to return it.

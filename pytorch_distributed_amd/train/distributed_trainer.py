@@ -82,14 +82,13 @@ class DistributedTrainer(Trainer):
             return loss
         return comm.all_reduce_mean_scalar(loss, device)
 
-    def _window_loss(self, device) -> float:
-        """The logged loss: mean over the accumulation window and over ranks. The 4-byte all-reduce
-        is issued on the communicator's reduction stream straight from the device-side
-        accumulator; the host blocks once, on the result."""
+    def _window_loss_handle(self, device):
+        """The logged loss: mean over the accumulation window and over ranks. The 4-byte all-reduce is
+        issued on the communicator's reduction queue straight from the device-side accumulator by
+        ALL ranks; nobody waits for it here — the line is printed a step later."""
         if not self.ddp_enabled or self.world_size == 1:
-            return super()._window_loss(device)
-        lazy = comm.LazyScalarMean(self.loss_accumulator / self.grad_accumulation_steps)
-        return lazy.value()
+            return super()._window_loss_handle(device)
+        return comm.LazyScalarMean(self.loss_accumulator / self.grad_accumulation_steps)
 
     # Checkpoints: state is gathered by all ranks (collective for sharded models); the base
     # class lets only rank 0 write the file.

@@ -8,9 +8,11 @@ reference trainer (assignments/assignment1/train/trainer.py:10-21,93-98,117-141)
 
 The loop itself is arranged for a GPU that should never wait for the host:
 
-* the loss of every micro-batch is accumulated in a device tensor and only read back
-  (one ``.item()``) on logging steps — the reference synchronises on every micro-batch
-  (trainer.py:79);
+* the loss of every micro-batch is accumulated in a device tensor; on logging steps it is
+  copied to pinned host memory on a side stream and the line is printed one optimizer step
+  later, when the copy has long completed — the host never drains the compute stream (the
+  reference synchronises on every micro-batch: trainer.py:79). Step times for tokens/s come
+  from device events recorded at the logging steps;
 * when the model supports it, ``model(inputs, targets)`` returns the loss through the
   fused LM-head + cross-entropy op instead of materialising logits;
 * with :class:`~pytorch_distributed_amd.optim.FusedAdamW` the gradients are cleared
@@ -72,6 +74,8 @@ class Trainer:
         self.start_time = None
         self._tokens_since_log = 0
         self._time_of_last_log = None
+        self._event_of_last_log = None
+        self._pending_log = None  # the logging step whose line has not been printed yet
         self._dataloader = None
         self._resume_data_state = None  # stream position from a loaded checkpoint, applied by train()
 
@@ -124,30 +128,60 @@ class Trainer:
     def _elapsed(self) -> float:
         return time.time() - self.start_time
 
-    def _throughput_fields(self, device) -> dict:
-        """tokens/s and MFU since the previous log line (whole job)."""
-        now = time.time()
-        if device.type == "cuda":
-            torch.cuda.synchronize(device)
-            now = time.time()
+    def _throughput_fields(self, pending: dict) -> dict:
+        """tokens/s and MFU between the previous logging step and this one (whole job). On a GPU the
+        interval is measured between device events recorded at the two logging steps, so no host
+        synchronisation is needed to make it exact."""
         fields = {}
-        if self._time_of_last_log is not None and now > self._time_of_last_log and self._tokens_since_log:
-            tps = self._tokens_since_log / (now - self._time_of_last_log)
+        seconds = None
+        ev, prev_ev = pending.get("event"), pending.get("prev_event")
+        if ev is not None and prev_ev is not None:
+            ev.synchronize()
+            seconds = prev_ev.elapsed_time(ev) * 1e-3
+        elif pending.get("prev_time") is not None:
+            if ev is not None:
+                ev.synchronize()
+                seconds = time.time() - pending["prev_time"]  # first interval: from the first batch to "step done"
+            else:
+                seconds = pending["host_time"] - pending["prev_time"]
+        if seconds and seconds > 0 and pending["tokens"]:
+            tps = pending["tokens"] / seconds
             fields["tok/s"] = tps
             if self._flops_per_token is None:
                 self._flops_per_token = model_flops_per_token(unwrap_model(self.model), self._seq_len)
             if self._flops_per_token:
                 fields["mfu"] = mfu(tps, self._flops_per_token, self.world_size)
+        device = pending["device"]
         if device.type == "cuda":
             fields["mem_gb"] = torch.cuda.max_memory_allocated(device) / 2**30
-        self._time_of_last_log = now
-        self._tokens_since_log = 0
         return fields
 
-    def _log(self, loss_value: float, device) -> None:
-        extra = self._throughput_fields(device)
-        line = (f"step={self.current_step} | loss={loss_value:.4f} | lr={self._current_lr():.2e} | "
-                f"time={self._elapsed():.1f}s")
+    def _queue_log(self, device) -> None:
+        """A logging step has been enqueued: start the read-back of its loss and remember what its line
+        needs. The line is printed by :meth:`_flush_log` once the NEXT optimizer step has been enqueued
+        (or training ends), so reading the value never stalls the stream."""
+        self._flush_log()
+        pending = {"step": self.current_step, "lr": self._current_lr(), "elapsed": self._elapsed(),
+                   "loss": self._window_loss_handle(device), "tokens": self._tokens_since_log, "device": device,
+                   "host_time": time.time(), "prev_time": self._time_of_last_log,
+                   "prev_event": self._event_of_last_log, "event": None}
+        if device.type == "cuda":
+            pending["event"] = torch.cuda.Event(enable_timing=True)
+            pending["event"].record(torch.cuda.current_stream(device))
+        self._event_of_last_log = pending["event"]
+        self._time_of_last_log = pending["host_time"]
+        self._tokens_since_log = 0
+        self._pending_log = pending
+
+    def _flush_log(self) -> None:
+        pending, self._pending_log = self._pending_log, None
+        if pending is None:
+            return
+        handle = pending["loss"]
+        loss_value = handle.value() if hasattr(handle, "value") else float(handle)
+        extra = self._throughput_fields(pending)
+        line = (f"step={pending['step']} | loss={loss_value:.4f} | lr={pending['lr']:.2e} | "
+                f"time={pending['elapsed']:.1f}s")
         if "tok/s" in extra:
             line += f" | tok/s={extra['tok/s']:.0f}"
         if "mfu" in extra:
@@ -158,16 +192,21 @@ class Trainer:
             print(line, flush=True)
             if self.metrics_file:
                 with open(self.metrics_file, "a") as f:
-                    f.write(json.dumps({"step": self.current_step, "loss": loss_value, "lr": self._current_lr(),
-                                        "time_s": self._elapsed(), **extra}) + "\n")
+                    f.write(json.dumps({"step": pending["step"], "loss": loss_value, "lr": pending["lr"],
+                                        "time_s": pending["elapsed"], **extra}) + "\n")
 
     def _aggregate_loss(self, loss: float, device) -> float:
         return loss
 
+    def _window_loss_handle(self, device):
+        """The logged loss as something with ``.value()``: mean over the accumulation window, read back
+        through pinned host memory on a side stream (see ``parallel.comm.LazyScalarMean``)."""
+        from ..parallel.comm import LazyScalarMean
+        return LazyScalarMean(self.loss_accumulator / self.grad_accumulation_steps, reduce=False)
+
     def _window_loss(self, device) -> float:
-        """Mean loss of the accumulation window (the only host synchronisation of a logging step)."""
-        avg = float(self.loss_accumulator.item()) / self.grad_accumulation_steps
-        return self._aggregate_loss(avg, device)
+        """Mean loss of the accumulation window, read now (blocks the host)."""
+        return self._window_loss_handle(device).value()
 
     def _maybe_checkpoint(self) -> None:
         """Called after step index ``current_step - 1`` has completed. File names and the trigger
@@ -215,8 +254,9 @@ class Trainer:
 
             if is_last_microbatch:
                 self._optimizer_step()
+                self._flush_log()  # the previous logging step's line: its values arrived a step ago
                 if self.current_step % self.log_every_n_steps == 0:
-                    self._log(self._window_loss(device), device)
+                    self._queue_log(device)
                 self.loss_accumulator.zero_()
                 self.current_step += 1
                 self._maybe_checkpoint()
@@ -224,6 +264,7 @@ class Trainer:
             if profiler is not None:
                 profiler.step()
 
+        self._flush_log()
         if self.rank == 0:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()

@@ -1,50 +1,12 @@
-"""Pre-tuned hipBLASLt / rocBLAS solution choices for the GEMM shapes of the benchmark models.
+"""GEMM plan files.
 
-PyTorch's TunableOp can time every library solution for a GEMM shape and remember the
-fastest; ``tunableop_gfx950.csv`` holds the result of that search on an MI355X for the
-(forward, dgrad, wgrad) shapes of the shipped configurations. ``enable_tuned_gemms()``
-switches TunableOp to lookup-only mode with that file, so training uses the tuned choices
-without paying for a search; shapes that are not in the file use the library default.
-``tune(path)`` re-runs the search for whatever GEMMs execute afterwards.
-
-The file is only honoured when its validator lines (PyTorch, HIP, hipBLASLt, rocBLAS
-versions, GPU architecture) match the running stack.
+Every bf16 GEMM of the framework goes through the native planner (``csrc/runtime/gemm_planner.cpp``),
+which times the library's candidate algorithms the first time it meets a problem and identifies
+its choice by the library's solution index. :mod:`.gemm_plans` exports those choices to a JSON
+file and imports them again, so a job can start from decisions measured earlier instead of
+re-timing; no plan file ships with the package (timing in place measured as fast as an
+exhaustive offline search), and nothing here touches PyTorch's TunableOp.
 """
-from __future__ import annotations
+from . import gemm_plans  # noqa: F401
 
-import os
-
-import torch
-
-TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
-
-
-def enable_tuned_gemms(path: str = TUNED_FILE) -> bool:
-    """Lookup-only TunableOp with the shipped results. Returns False when unavailable."""
-    if not torch.cuda.is_available() or not os.path.exists(path) or os.environ.get("PDA_NO_TUNED_GEMMS") == "1":
-        return False
-    try:
-        tunable = torch.cuda.tunable
-        tunable.enable(True)
-        tunable.tuning_enable(False)
-        if hasattr(tunable, "write_file_on_exit"):
-            tunable.write_file_on_exit(False)
-        tunable.set_filename(path)
-        return bool(tunable.read_file(path))
-    except Exception:  # an incompatible file must never stop training
-        try:
-            torch.cuda.tunable.enable(False)
-        except Exception:
-            pass
-        return False
-
-
-def tune(path: str, max_tuning_duration_ms: int = 60) -> None:
-    """Search mode: every new GEMM shape executed from now on is tuned and recorded in ``path``."""
-    tunable = torch.cuda.tunable
-    tunable.enable(True)
-    tunable.tuning_enable(True)
-    tunable.set_max_tuning_duration(max_tuning_duration_ms)
-    tunable.set_filename(path)
-    if hasattr(tunable, "write_file_on_exit"):
-        tunable.write_file_on_exit(True)
+__all__ = ["gemm_plans"]

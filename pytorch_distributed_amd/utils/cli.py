@@ -54,7 +54,19 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
     ap.add_argument("--resume", default=None, help="checkpoint path, or 'latest' to pick the newest in --checkpoint-dir")
     ap.add_argument("--metrics-file", default=None)
     ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="selective")
+    ap.add_argument("--grad-accum-dtype", choices=["auto", "param", "fp32"], default="auto",
+                    help="distributed scripts: dtype in which the micro-batches of an accumulation window are "
+                         "summed; auto = fp32 when bf16 gradients are accumulated over more than one micro-batch "
+                         "(the reference accumulates in fp32), the parameter dtype otherwise")
     return ap
+
+
+def resolve_grad_accum_dtype(args, dtype, world_size: int = 1) -> str:
+    """'fp32' or 'param' from ``--grad-accum-dtype`` (see its help)."""
+    if args.grad_accum_dtype != "auto":
+        return args.grad_accum_dtype
+    steps = args.global_batch_size // max(1, args.micro_batch_size * world_size)
+    return "fp32" if dtype != torch.float32 and steps > 1 else "param"
 
 
 def resolve_dtype(args, device) -> torch.dtype:
@@ -75,7 +87,7 @@ def build_model(args, device, dtype):
     with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
         if hasattr(cfg, "intermediate_size"):
             from ..models.llama import LlamaForCausalLM
-            model = LlamaForCausalLM(cfg)
+            model = LlamaForCausalLM(cfg, activation_checkpoint=args.activation_checkpoint)
         else:
             model = MyGPT2LMHeadModel(cfg, activation_checkpoint=args.activation_checkpoint)
     return model.to(device=device, dtype=dtype), cfg

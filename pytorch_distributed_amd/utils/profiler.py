@@ -11,11 +11,14 @@ Backends:
 * ``"range"`` (the default) — the framework's own tracer (``csrc/runtime/range_tracer.cpp``):
   ``ProfilerStep#N`` plus named host + GPU ranges for forward / backward / optimizer (emitted by
   the trainers through :func:`annotate`) and for all-gather wait / reduce-scatter launch /
-  end-of-backward reduction wait (emitted by the C++ DDP / FSDP runtime itself), at negligible
-  overhead. Every range is mirrored to roctx, so when the run is wrapped in
-  ``rocprofv3 --kernel-trace --marker-trace`` the kernel rows and these ranges share one clock and
-  ``utils/rocprof_trace.py`` (``analyze_traces.py --from-rocprof``) merges them into the per-rank
-  Chrome trace with the collectives on a row of their own — the kernel-level trace without Kineto.
+  end-of-backward reduction wait (emitted by the C++ DDP / FSDP runtime itself), AND one row per
+  HIP queue with every kernel dispatch and memory copy of the active window, collectives on a
+  row of their own: ``csrc/runtime/kernel_tracer.cpp`` collects the GPU activity records in
+  process, switched on and off by this schedule, so the plain training command writes the
+  kernel-level trace (``kernels=False`` keeps ranges only). Every range is also mirrored to
+  roctx: when the run is wrapped in ``rocprofv3 --kernel-trace --marker-trace`` (the route to
+  hardware counters) the in-process collection stays off and ``utils/rocprof_trace.py``
+  (``analyze_traces.py --from-rocprof``) merges rocprofv3's kernel rows with these ranges.
 * ``"kineto"`` — ``torch.profiler`` (roctracer underneath on ROCm), kept for comparison.
 * ``"auto"`` — the same as ``"range"``.
 
@@ -50,7 +53,7 @@ def annotate(name: str):
 class StepProfiler:
     def __init__(self, wait: int = 2, warmup: int = 2, active: int = 6, repeat: int = 1,
                  trace_path: Optional[str] = None, backend: str = "auto", rank: int = 0,
-                 record_shapes: bool = False):
+                 record_shapes: bool = False, kernels: bool = True):
         if backend == "auto":
             backend = "range"
         if backend not in ("kineto", "range"):
@@ -64,6 +67,8 @@ class StepProfiler:
         self._kineto = None
         self._tracer = None
         self._step_open = False
+        self.collects_kernels = False
+        self.kernels_written = 0
         if trace_path:
             os.makedirs(os.path.dirname(os.path.abspath(trace_path)), exist_ok=True)
         if backend == "kineto":
@@ -74,8 +79,12 @@ class StepProfiler:
                                    schedule=schedule(wait=wait, warmup=warmup, active=active, repeat=repeat),
                                    on_trace_ready=self._kineto_ready)
         else:
-            self._tracer = _ext.require().RangeTracer(torch.cuda.is_available())
+            self._tracer = _ext.require().RangeTracer(torch.cuda.is_available(), bool(kernels))
             self._tracer.set_enabled(False)
+            self.collects_kernels = bool(self._tracer.collects_kernels)
+            if kernels and torch.cuda.is_available() and not self.collects_kernels and rank == 0:
+                print("[profiler] kernel rows unavailable (%s): the trace will hold ranges only"
+                      % _ext.require().kernel_trace_unavailable_reason(), flush=True)
 
     # -- schedule ------------------------------------------------------------------------
     def _phase(self, step: int) -> str:
@@ -131,11 +140,12 @@ class StepProfiler:
             self._step_open = False
 
     def _flush_range_trace(self) -> None:
+        self._tracer.set_enabled(False)  # closes the kernel-collection window: drains the device, takes the records
         if self._tracer.num_ranges and self.trace_path:
             self._tracer.save(self.trace_path, self.rank)
             self.traces_written += 1
+            self.kernels_written = int(self._tracer.num_kernels)
         self._tracer.clear()
-        self._tracer.set_enabled(False)
 
     def step(self) -> None:
         """Marks the end of one profiling step (the trainer calls this once per micro-batch)."""

@@ -112,3 +112,152 @@ def test_fabric_measurement_and_self_test_run_on_the_rccl_communicator(pg):
         assert len(rows) == 2 and all(t > 0 for _, t in rows)
     policy = autotune.choose_policy(m, total_grad_bytes=1 << 30)
     assert policy.ddp_bucket_mb > 0 and policy.fits
+
+
+# ------------------------------------------------------------------ exact collective counts on the real streams
+def _comm_counts():
+    from pytorch_distributed_amd.parallel import comm
+
+    k = comm.get_communicator().counters()
+    return {n: int(k[n]) for n in ("all_gather", "reduce_scatter", "all_reduce", "broadcast")}
+
+
+def _delta(before):
+    after = _comm_counts()
+    return {n: after[n] - before[n] for n in after}
+
+
+# 4 optimizer steps of 2 micro-batches (the first under no_sync); U block units + the root unit.
+# FULL_SHARD, per step: the root is gathered once (it stays gathered until the synchronising backward
+# ends), every block unit in each forward and again in each backward: 1 + 4 U all-gathers; one
+# reduce-scatter per unit.
+# With every block resident the backward all-gathers disappear: 1 + 2 U.
+@pytest.mark.parametrize("n_layer,unit_blocks,resident,all_gathers_per_step", [
+    (3, 1, 0.0, 1 + 4 * 3), (6, 3, 0.0, 1 + 4 * 2), (3, 1, "auto", 1 + 2 * 3)])
+def test_fsdp_full_shard_exact_collective_counts(pg, n_layer, unit_blocks, resident, all_gathers_per_step):
+    from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
+
+    base, cfg = _model(2, n_layer=n_layer)
+    ids = _ids(cfg, 8, seed=2)
+    ref_losses = _train(base, base.parameters(), ids)
+    model, _ = _model(2, n_layer=n_layer)
+    fsdp = fsdp_wrap_gpt(model, ShardingStrategy.FULL_SHARD, unit_blocks=unit_blocks, force_collectives=True,
+                         resident_gb=resident)
+    before = _comm_counts()
+    losses = _train(fsdp, fsdp.parameters(), ids, no_sync=fsdp.no_sync)
+    got = _delta(before)
+    n_units = 1 + n_layer // unit_blocks
+    assert got["all_gather"] == 4 * all_gathers_per_step, got
+    assert got["reduce_scatter"] == 4 * n_units and got["all_reduce"] == 0, got
+    if resident == "auto":
+        assert fsdp.resident_units == n_layer
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-2, (losses, ref_losses)
+
+
+def test_ddp_decomposed_reduction_exact_counts(pg):
+    from pytorch_distributed_amd.parallel import DDP
+
+    base, cfg = _model(3)
+    ids = _ids(cfg, 8, seed=3)
+    ref_losses = _train(base, base.parameters(), ids)
+    model, _ = _model(3)
+    ddp = DDP(model, device_ids=[0], bucket_cap_mb=8, first_bucket_mb=1, force_collectives=True, decompose=True)
+    before = _comm_counts()
+    losses = _train(ddp, ddp.parameters(), ids, no_sync=ddp.no_sync)
+    got = _delta(before)
+    nb = ddp.reducer.num_buckets
+    # world size 1: a bucket's "reduce-scatter + all-gather" degenerates to the all-reduce branch
+    assert got["all_reduce"] + got["reduce_scatter"] == 4 * nb and got["all_gather"] in (0, 4 * nb), (got, nb)
+    assert ddp.reducer.num_collectives == 4 * nb
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-2, (losses, ref_losses)
+
+
+@pytest.mark.parametrize("wrapper", ["ddp", "fsdp"])
+def test_fp32_gradient_accumulation_on_the_gpu_sinks(pg, wrapper):
+    """grad_accum_dtype='fp32': the weight-gradient kernels write fp32 slices of the wrapper's buffer
+    (bf16 parameters), other gradients are folded by the hooks; training matches the plain model."""
+    from pytorch_distributed_amd.parallel import DDP, ShardingStrategy, fsdp_wrap_gpt
+
+    base, cfg = _model(4)
+    ids = _ids(cfg, 8, seed=4)
+    ref_losses = _train(base, base.parameters(), ids)
+    model, _ = _model(4)
+    if wrapper == "ddp":
+        wrapped = DDP(model, device_ids=[0], bucket_cap_mb=8, first_bucket_mb=1, force_collectives=True,
+                      grad_accum_dtype="fp32")
+        assert all(t is not None and t.dtype == torch.float32 for t in wrapped.reducer.accum_tensors())
+    else:
+        wrapped = fsdp_wrap_gpt(model, ShardingStrategy.FULL_SHARD, force_collectives=True, grad_accum_dtype="fp32")
+        assert all(m.unit.accumulates_fp32() for m in wrapped.modules() if type(m).__name__ == "FSDP")
+    losses = _train(wrapped, wrapped.parameters(), ids, no_sync=wrapped.no_sync)
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-2, (losses, ref_losses)
+    sd, ref_sd = wrapped.state_dict(), base.state_dict()
+    for k in ref_sd:
+        assert (sd[k].float().cpu() - ref_sd[k].float().cpu()).abs().max().item() < 1e-2, k
+
+
+def test_second_library_communicator_for_the_gather_queue():
+    """An RCCL communicator with its own library communicator for all-gathers: both routes give the
+    same results, and the start-up measurement that chooses between them runs."""
+    from pytorch_distributed_amd import _ext
+    from pytorch_distributed_amd.parallel import autotune
+
+    ext = _ext.require()
+    torch.cuda.set_device(0)
+    c = ext.create_communicator("rccl", 0, 1, "127.0.0.1", 29733, 0, 60.0, "dual-test", True)
+    try:
+        assert c.has_dual() and c.dual_route()
+        for route in (True, False):
+            c.set_dual_route(route)
+            src = torch.arange(4096, device=DEV, dtype=torch.bfloat16)
+            out = torch.zeros(4096, device=DEV, dtype=torch.bfloat16)
+            rs_in = torch.full((1 << 20,), 2.0, device=DEV)
+            rs_out = torch.empty(1 << 20, device=DEV)
+            w1 = c.reduce_scatter(rs_out, rs_in, "avg", 1)
+            w2 = c.all_gather(out, src, 0)
+            w2.wait()
+            w1.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(out, src) and bool((rs_out == 2.0).all())
+        got = autotune.measure_gather_behind_reduce(c, torch.device("cuda", 0), reduce_mb=16, gather_mb=2, iters=2)
+        assert set(got) == {"shared", "dual"} and all(g > 0 and p >= g * 0.5 for g, p in got.values())
+        assert not c.dual_route()  # the measurement leaves the route as it found it
+    finally:
+        c.close()
+
+
+def test_in_process_kernel_trace(tmp_path):
+    """StepProfiler alone (no external profiler): the active window's kernel dispatches land in the
+    Chrome trace next to the ranges, and the analyzer reads it."""
+    from pytorch_distributed_amd import _ext
+    from pytorch_distributed_amd.utils import StepProfiler
+    from pytorch_distributed_amd.utils import trace_analysis as ta
+
+    if not _ext.require().kernel_trace_available():
+        pytest.fail("in-process kernel tracing unavailable: " + _ext.require().kernel_trace_unavailable_reason())
+    model, cfg = _model(5, n_layer=2)
+    ids = _ids(cfg, 6, seed=5)
+    path = str(tmp_path / "rank0_trace.json")
+    with StepProfiler(wait=1, warmup=1, active=3, repeat=1, trace_path=path) as prof:
+        assert prof.collects_kernels
+        for x in ids:
+            with prof.range("forward"):
+                loss = model(x[:, :-1], x[:, 1:])
+            with prof.range("backward"):
+                loss.backward()
+            prof.step()
+    assert prof.traces_written == 1 and prof.kernels_written > 50
+    ev = ta.load_trace(path)
+    steps = sorted(e["name"] for e in ev if e.get("name", "").startswith("ProfilerStep#") and e.get("tid") == 0)
+    assert steps == ["ProfilerStep#2", "ProfilerStep#3", "ProfilerStep#4"]
+    kernels = [e for e in ev if e.get("cat") == "kernel"]
+    names = " ".join(e["name"] for e in kernels)
+    assert "attn_fwd_kernel" in names and "wgrad" in names, names[:2000]
+    win = ta.step_window(ev, 3)
+    inside = [k for k in kernels if win[0] <= k["ts"] <= win[1]]
+    assert len(inside) > 10                                  # kernel rows sit on the ranges' clock
+    tb = ta.temporal_breakdown(ev, step=3)
+    assert tb["compute_us"] > 0 and tb["compute_pct"] > 20, tb
+    # nothing from the wait / warm-up steps was collected
+    first = min(k["ts"] for k in kernels)
+    assert first >= ta.step_window(ev, 2)[0] - 2000, (first, ta.step_window(ev, 2))

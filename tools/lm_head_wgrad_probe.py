@@ -3,8 +3,6 @@ view, the GEMM planner with a transposed first operand, and the native split-K k
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_distributed_amd import _ext
-from pytorch_distributed_amd.tuning import enable_tuned_gemms
-enable_tuned_gemms()
 ext = _ext.require()
 M, V, vp, d = 32768, 50257, 50304, 1280
 dl = torch.zeros(M, vp, device="cuda", dtype=torch.bfloat16); dl[:, :V] = torch.randn(M, V, device="cuda", dtype=torch.bfloat16) * 0.01

@@ -10,8 +10,13 @@ fabric unless given (``--bucket-mb``, ``--ddp-decompose``).
 """
 import argparse
 import os
+import time
 
-import torch
+from pytorch_distributed_amd.parallel.comm import prepare_multiprocess_env
+
+prepare_multiprocess_env()  # before anything initialises the HIP runtime
+
+import torch  # noqa: E402
 
 from pytorch_distributed_amd.parallel import DDP, autotune, init_distributed, plan_sync, shutdown
 from pytorch_distributed_amd.train import DistributedTrainer
@@ -19,11 +24,12 @@ from pytorch_distributed_amd.utils import StepProfiler, cli
 from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
-def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False, decompose=None, force_collectives=False):
+def setup_ddp_model(model, device, bucket_cap_mb=None, reduce_fp32=False, decompose=None, force_collectives=False,
+                    grad_accum_dtype=None):
     """``model`` (already on ``device``) wrapped in DDP (None = the start-up measurement's choice)."""
     ids = [device.index] if device.type == "cuda" else None
     return DDP(model, device_ids=ids, reduce_fp32=reduce_fp32, bucket_cap_mb=bucket_cap_mb, decompose=decompose,
-               force_collectives=force_collectives)
+               force_collectives=force_collectives, grad_accum_dtype=grad_accum_dtype)
 
 
 def main():
@@ -35,9 +41,17 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="issue the collectives even at world size 1 (single-GPU rehearsal of the communication path)")
     ap.add_argument("--backend", default=None, choices=[None, "rccl", "socket", "c10d", "nccl", "gloo"])
+    ap.add_argument("--no-comm-fallback", action="store_true",
+                    help="fail instead of switching to a torch.distributed group when the native communicator does "
+                         "not pass its start-up self-test on every rank")
+    ap.add_argument("--comm-dual", action="store_true",
+                    help="RCCL: a second library communicator for the all-gather queue (gathers and reductions "
+                         "run concurrently; with the start-up autotune, only if measured faster)")
     ap.add_argument("--reduce-fp32", action="store_true", help="all-reduce bf16 gradients through an fp32 copy")
     args = ap.parse_args()
-    rank, world, device = init_distributed(args.backend)
+    native = args.backend in (None, "rccl", "nccl", "socket", "gloo")
+    rank, world, device = init_distributed(args.backend, fallback=None if args.no_comm_fallback or not native else "c10d",
+                                           dual=args.comm_dual or None)
     dtype = cli.resolve_dtype(args, device)
     if rank == 0:
         print(f"\nDDP Configuration:\nGlobal batch size: {args.global_batch_size}\n"
@@ -49,10 +63,12 @@ def main():
     if device.type == "cuda" and dtype == torch.bfloat16:
         plan_sync.plan_gemms(model, args.micro_batch_size, args.sequence_length, cfg.vocab_size)
     model = setup_ddp_model(model, device, args.bucket_mb, args.reduce_fp32,
-                            {"auto": None, "on": True, "off": False}[args.ddp_decompose], args.force_collectives)
+                            {"auto": None, "on": True, "off": False}[args.ddp_decompose], args.force_collectives,
+                            grad_accum_dtype=cli.resolve_grad_accum_dtype(args, dtype, world))
     if rank == 0:
         print(f"Model wrapped with DDP ({model.reducer.num_buckets} gradient buckets of <= {model.bucket_cap_mb:g} MiB"
-              f"{', reduce-scatter + all-gather' if model.decompose else ''})")
+              f"{', reduce-scatter + all-gather' if model.decompose else ''}"
+              f"{', fp32 gradient accumulation' if model.grad_accum_dtype == 'fp32' else ''})")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
     optimizer, scheduler = cli.build_optimizer(args, model.parameters())
     trainer = DistributedTrainer(model, optimizer, scheduler, max_steps=args.max_steps,

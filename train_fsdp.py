@@ -10,8 +10,13 @@ reference's wrapping, on a single rank or with ``--no-comm-autotune``).
 """
 import argparse
 import os
+import time
 
-import torch
+from pytorch_distributed_amd.parallel.comm import prepare_multiprocess_env
+
+prepare_multiprocess_env()  # before anything initialises the HIP runtime
+
+import torch  # noqa: E402
 
 from pytorch_distributed_amd.parallel import (FSDP, ShardingStrategy, autotune, fsdp_wrap_gpt, init_distributed,
                                               plan_sync, shutdown)
@@ -21,11 +26,12 @@ from pytorch_distributed_amd.utils.profiler import null_profiler
 
 
 def setup_fsdp_model(model, device, sharding_strategy_name="FULL_SHARD", unit_blocks=1, reduce_fp32=False,
-                     force_collectives=False, resident_gb=0.0):
+                     force_collectives=False, resident_gb=0.0, grad_accum_dtype=None):
     """Per-block wrapping plus the root unit (the reference's layout when ``unit_blocks == 1``)."""
     model = model.to(device)
     strategy = ShardingStrategy[sharding_strategy_name]
-    kw = dict(reduce_fp32=reduce_fp32, force_collectives=force_collectives, resident_gb=resident_gb)
+    kw = dict(reduce_fp32=reduce_fp32, force_collectives=force_collectives, resident_gb=resident_gb,
+              grad_accum_dtype=grad_accum_dtype)
     if unit_blocks == 1:
         for i, block in enumerate(model.transformer.h):
             model.transformer.h[i] = FSDP(block, sharding_strategy=strategy, **kw)
@@ -47,10 +53,21 @@ def main():
                     help="issue the collectives even at world size 1 (single-GPU rehearsal of the communication path)")
     ap.add_argument("--reduce-fp32", action="store_true", help="reduce bf16 gradients through an fp32 copy")
     ap.add_argument("--backend", default=None, choices=[None, "rccl", "socket", "c10d", "nccl", "gloo"])
+    ap.add_argument("--no-comm-fallback", action="store_true",
+                    help="fail instead of switching to a torch.distributed group when the native communicator does "
+                         "not pass its start-up self-test on every rank")
+    ap.add_argument("--comm-dual", action="store_true",
+                    help="RCCL: a second library communicator for the all-gather queue (gathers and reductions "
+                         "run concurrently; with the start-up autotune, only if measured faster)")
     ap.add_argument("--sharded-checkpoint", default=None,
                     help="directory: also write a per-rank sharded checkpoint at the end of training")
+    ap.add_argument("--resume-sharded", default=None,
+                    help="directory of a sharded checkpoint (written with --sharded-checkpoint, at any world size) to "
+                         "continue from: parameters, sharded optimizer state, step and schedule")
     args = ap.parse_args()
-    rank, world, device = init_distributed(args.backend)
+    native = args.backend in (None, "rccl", "nccl", "socket", "gloo")
+    rank, world, device = init_distributed(args.backend, fallback=None if args.no_comm_fallback or not native else "c10d",
+                                           dual=args.comm_dual or None)
     dtype = cli.resolve_dtype(args, device)
     if rank == 0:
         print(f"\nFSDP Configuration:\nSharding strategy: {args.strategy}\n"
@@ -67,7 +84,7 @@ def main():
         unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
     resident = "auto" if args.fsdp_resident_gb == "auto" else float(args.fsdp_resident_gb)
     model = setup_fsdp_model(model, device, args.strategy, unit_blocks, args.reduce_fp32, args.force_collectives,
-                             resident_gb=resident)
+                             resident_gb=resident, grad_accum_dtype=cli.resolve_grad_accum_dtype(args, dtype, world))
     if rank == 0:
         print(f"Model wrapped with FSDP ({args.strategy}, {unit_blocks} block(s) per unit)")
     loader = cli.build_loader(args, cfg, device, distributed=True, rank=rank)
@@ -80,6 +97,16 @@ def main():
     resume = cli.resolve_resume(args)
     if resume:
         trainer.load_checkpoint(resume)
+    if args.resume_sharded:
+        from pytorch_distributed_amd.parallel.checkpoint import load_sharded_checkpoint
+        t0 = time.time()
+        trainer.current_step = load_sharded_checkpoint(args.resume_sharded, model, optimizer, lr_scheduler=scheduler)
+        trainer.batch_count = trainer.current_step * trainer.grad_accumulation_steps
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if rank == 0:
+            print(f"Loaded sharded checkpoint {args.resume_sharded} (step {trainer.current_step}) in "
+                  f"{time.time() - t0:.1f}s")
     trace_dir = args.trace_dir or f"outputs/traces/fsdp_{args.strategy.lower()}"
     prof = null_profiler() if args.no_profile else StepProfiler(
         wait=2, warmup=2, active=6, repeat=1, trace_path=os.path.join(trace_dir, f"rank{rank}_trace.json"),
@@ -88,8 +115,11 @@ def main():
         trainer.train(loader, profiler=p)
     if args.sharded_checkpoint:
         from pytorch_distributed_amd.parallel.checkpoint import save_sharded_checkpoint
+        t0 = time.time()
         save_sharded_checkpoint(args.sharded_checkpoint, model, optimizer, step=trainer.current_step,
                                 lr_scheduler=scheduler)
+        if rank == 0:
+            print(f"Saved sharded checkpoint to {args.sharded_checkpoint} in {time.time() - t0:.1f}s")
     if rank == 0:
         print(f"FSDP training with {args.strategy} completed!")
         if not args.no_profile:
