@@ -2,6 +2,13 @@
 // libroctracer64 that is already in the process (PyTorch ships and loads one), so nothing links
 // against a second copy of the HIP runtime and a box without the library only loses kernel rows.
 //
+// Delivery is asynchronous: the HIP runtime files a dispatch's device-side record some time after
+// the dispatch has completed (when it retires the command), not when the host observes completion,
+// so a record can arrive after hipDeviceSynchronize() has returned. stop() therefore keeps the
+// domains enabled and flushes until the device-side record of the LAST kernel launch of the window
+// (matched by correlation id with the launch call's own record) has arrived, bounded by a time-out;
+// disabling right after the synchronisation loses everything since the last retirement.
+//
 // Life cycle: the first start() opens a memory pool of our own (never roctracer's default pool,
 // which another tool in the process may own). A window enables the HIP_OPS activity domain on
 // that pool; stop() disables it and flushes, and the pool's buffer callback — run on the
@@ -14,8 +21,11 @@
 #include <roctracer/roctracer.h>
 #include <roctracer/roctracer_hip.h>
 
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 namespace pda {
@@ -31,6 +41,7 @@ struct Api {
   using next_record_t = roctracer_status_t (*)(const activity_record_t*, const activity_record_t**);
   using get_timestamp_t = roctracer_status_t (*)(roctracer_timestamp_t*);
   using error_string_t = const char* (*)();
+  using op_string_t = const char* (*)(uint32_t, uint32_t, uint32_t);
 
   open_pool_expl_t open_pool = nullptr;
   close_pool_expl_t close_pool = nullptr;
@@ -40,6 +51,7 @@ struct Api {
   next_record_t next_record = nullptr;
   get_timestamp_t get_timestamp = nullptr;
   error_string_t error_string = nullptr;
+  op_string_t op_string = nullptr;
   std::string why;
   bool ok = false;
 
@@ -76,6 +88,7 @@ struct Api {
     next_record = reinterpret_cast<next_record_t>(sym("roctracer_next_record"));
     get_timestamp = reinterpret_cast<get_timestamp_t>(sym("roctracer_get_timestamp"));
     error_string = reinterpret_cast<error_string_t>(sym("roctracer_error_string"));
+    op_string = reinterpret_cast<op_string_t>(sym("roctracer_op_string"));
     ok = why.empty();
   }
 };
@@ -91,6 +104,10 @@ struct State {
   bool collecting = false;
   std::vector<Activity> records;
   std::unordered_map<std::string, std::string> demangled;
+  uint64_t seen_records = 0, seen_buffers = 0, seen_other = 0;  // diagnosis: everything the callback was handed
+  bool keep_api = false;  // keep the host-side API call records too (a row of launches in the trace)
+  uint64_t max_launch_corr = 0;  // highest correlation id of a kernel-launch API call seen in this window
+  uint64_t max_op_corr = 0;      // highest correlation id of a device-side record seen in this window
 };
 
 State& state() {
@@ -110,12 +127,43 @@ const std::string& pretty_name(State& st, const char* mangled) {
   return st.demangled.emplace(mangled, std::move(out)).first->second;
 }
 
+// API calls that say something about the timeline (launches, copies, fences); the hundreds of
+// hipGetDevice / attribute queries libraries make per call are dropped.
+bool worth_a_row(const char* name) {
+  if (name == nullptr || std::strstr(name, "CallConfiguration") != nullptr) return false;
+  for (const char* key : {"Launch", "Memcpy", "Memset", "Synchronize", "EventRecord", "StreamWaitEvent", "Malloc", "Free"})
+    if (std::strstr(name, key) != nullptr) return true;
+  return false;
+}
+
 void on_buffer(const char* begin, const char* end, void* /*arg*/) {
   State& st = state();
   std::lock_guard<std::mutex> lk(st.mu);
   const activity_record_t* rec = reinterpret_cast<const activity_record_t*>(begin);
   const activity_record_t* last = reinterpret_cast<const activity_record_t*>(end);
+  ++st.seen_buffers;
   while (rec < last) {
+    ++st.seen_records;
+    if (rec->domain != ACTIVITY_DOMAIN_HIP_OPS) ++st.seen_other;
+    if (rec->domain == ACTIVITY_DOMAIN_HIP_API) {
+      const char* n = api().op_string ? api().op_string(ACTIVITY_DOMAIN_HIP_API, rec->op, rec->kind) : nullptr;
+      if (n != nullptr && std::strstr(n, "Launch") != nullptr && std::strstr(n, "CallConfiguration") == nullptr &&
+          rec->correlation_id > st.max_launch_corr)
+        st.max_launch_corr = rec->correlation_id;
+    }
+    if (rec->domain == ACTIVITY_DOMAIN_HIP_OPS && rec->correlation_id > st.max_op_corr) st.max_op_corr = rec->correlation_id;
+    if (rec->domain == ACTIVITY_DOMAIN_HIP_API && rec->end_ns >= rec->begin_ns && st.keep_api &&
+        worth_a_row(api().op_string ? api().op_string(ACTIVITY_DOMAIN_HIP_API, rec->op, rec->kind) : nullptr)) {
+      Activity a;
+      a.kind = Activity::kApi;
+      a.begin_ns = rec->begin_ns;
+      a.end_ns = rec->end_ns;
+      a.correlation = rec->correlation_id;
+      a.queue = rec->thread_id;  // host thread of the call
+      const char* n = api().op_string ? api().op_string(ACTIVITY_DOMAIN_HIP_API, rec->op, rec->kind) : nullptr;
+      a.name = n != nullptr ? n : "hip api";
+      st.records.push_back(std::move(a));
+    }
     if (rec->domain == ACTIVITY_DOMAIN_HIP_OPS && rec->end_ns >= rec->begin_ns) {
       Activity a;
       a.begin_ns = rec->begin_ns;
@@ -152,7 +200,7 @@ bool collecting() {
   return st.collecting;
 }
 
-bool start() {
+bool start(bool keep_api_calls) {
   Api& a = api();
   if (!a.ok) return false;
   State& st = state();
@@ -172,8 +220,14 @@ bool start() {
       }
     }
     st.records.clear();
+    st.keep_api = keep_api_calls;
+    st.max_launch_corr = st.max_op_corr = 0;
   }
-  if (a.enable_domain(ACTIVITY_DOMAIN_HIP_OPS, st.pool) != ROCTRACER_STATUS_SUCCESS) {
+  // The HIP runtime only reports a kernel's device-side record when the API call that launched it
+  // is being traced as well (the call is what carries the correlation id the record is filed under):
+  // with the OPS domain alone, most dispatches of a single-stream program produce no record at all.
+  if (a.enable_domain(ACTIVITY_DOMAIN_HIP_API, st.pool) != ROCTRACER_STATUS_SUCCESS ||
+      a.enable_domain(ACTIVITY_DOMAIN_HIP_OPS, st.pool) != ROCTRACER_STATUS_SUCCESS) {
     a.why = std::string("roctracer_enable_domain_activity_expl failed: ") + (a.error_string ? a.error_string() : "?");
     a.ok = false;
     return false;
@@ -191,13 +245,31 @@ std::vector<Activity> stop() {
     if (!st.collecting) return {};
     st.collecting = false;
   }
-  // Not under the mutex: both calls can run the buffer callback, which takes it.
+  // Not under the mutex: these calls can run the buffer callback, which takes it.
+  // Wait (bounded) for the device-side record of the window's last kernel launch: see the header comment.
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(3000);
+  for (;;) {
+    a.flush(st.pool);
+    {
+      std::lock_guard<std::mutex> lk(st.mu);
+      if (st.max_op_corr >= st.max_launch_corr) break;
+    }
+    if (std::chrono::steady_clock::now() > deadline) break;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
   a.disable_domain(ACTIVITY_DOMAIN_HIP_OPS);
+  a.disable_domain(ACTIVITY_DOMAIN_HIP_API);
   a.flush(st.pool);
   std::lock_guard<std::mutex> lk(st.mu);
   std::vector<Activity> out;
   out.swap(st.records);
   return out;
+}
+
+std::vector<uint64_t> debug_counts() {
+  State& st = state();
+  std::lock_guard<std::mutex> lk(st.mu);
+  return {st.seen_buffers, st.seen_records, st.seen_other, st.max_launch_corr, st.max_op_corr};
 }
 
 uint64_t now_ns() {

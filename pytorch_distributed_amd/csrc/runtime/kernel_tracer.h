@@ -15,13 +15,13 @@ namespace pda {
 namespace ktrace {
 
 struct Activity {
-  enum Kind : int { kKernel = 0, kCopy = 1, kBarrier = 2 };
+  enum Kind : int { kKernel = 0, kCopy = 1, kBarrier = 2, kApi = 3 };
   int kind = kKernel;
   std::string name;       // demangled kernel name, or the copy's description
   uint64_t begin_ns = 0;  // roctracer clock
   uint64_t end_ns = 0;
   int device = 0;
-  uint64_t queue = 0;  // HIP stream / hardware queue id as the runtime reports it
+  uint64_t queue = 0;  // HIP stream / hardware queue id as the runtime reports it (kApi: the host thread id)
   uint64_t correlation = 0;
   uint64_t bytes = 0;  // copies only
 };
@@ -33,8 +33,9 @@ std::string unavailable_reason();
 
 // Opens a collection window: every kernel dispatch and copy that COMPLETES on the GPU from now
 // until stop() is recorded. Returns false (and records nothing) when the API is unavailable or
-// a window is already open.
-bool start();
+// a window is already open. `keep_api_calls`: also keep one record per HIP API call (hipLaunchKernel,
+// hipMemcpyAsync, ...) with the correlation id it shares with the device-side record it caused.
+bool start(bool keep_api_calls = false);
 // Closes the window, flushes the library's buffers and returns what was collected, in completion
 // order. Safe to call without a matching start (returns an empty vector).
 std::vector<Activity> stop();
@@ -43,6 +44,9 @@ bool collecting();
 // Nanoseconds on the clock the records use (0 when unavailable): sampled next to the host clock
 // to place the records on a host timeline.
 uint64_t now_ns();
+
+// Diagnosis: {buffers, records, records of other domains} the library's callback has delivered so far.
+std::vector<uint64_t> debug_counts();
 
 }  // namespace ktrace
 }  // namespace pda

@@ -136,7 +136,7 @@ class RangeTracer {
     if (kernels_ && e && !enabled_ && !pda::ktrace::collecting()) {
       const uint64_t k0 = pda::ktrace::now_ns();
       const double h0 = now_us();
-      if (pda::ktrace::start()) {
+      if (pda::ktrace::start(/*keep_api_calls=*/true)) {
         window_k0_ns_ = k0;
         window_h0_us_ = h0;
         window_open_ = true;
@@ -150,6 +150,8 @@ class RangeTracer {
         k.ts_us = window_h0_us_ + (double(a.begin_ns) - double(window_k0_ns_)) * 1e-3;
         k.dur_us = double(a.end_ns - a.begin_ns) * 1e-3;
         k.copy = a.kind == pda::ktrace::Activity::kCopy;
+        k.api = a.kind == pda::ktrace::Activity::kApi;
+        k.correlation = a.correlation;
         k.queue = a.queue;
         k.bytes = a.bytes;
         k.name = std::move(a.name);
@@ -161,7 +163,11 @@ class RangeTracer {
   }
   bool enabled() const { return enabled_; }
   bool collects_kernels() const { return kernels_; }
-  int64_t num_kernels() const { return (int64_t)kernels_done_.size(); }
+  int64_t num_kernels() const {
+    int64_t n = 0;
+    for (auto& k : kernels_done_) n += k.api ? 0 : 1;
+    return n;
+  }
 
   void push(const std::string& name, const std::string& cat) {
     if (roctx().push) roctx().push(name.c_str());
@@ -243,12 +249,20 @@ class RangeTracer {
       }
     }
     // Kernel rows: one per HIP queue in order of first appearance, collectives on a row of their own.
-    std::map<uint64_t, int> queue_row;
+    std::map<uint64_t, int> queue_row, api_row;
     bool any_collective = false;
     for (auto& k : kernels_done_) {
-      if (!k.copy && is_collective_name(k.name)) any_collective = true;
-      else if (!queue_row.count(k.queue)) queue_row.emplace(k.queue, 100 + (int)queue_row.size());
+      if (k.api) {
+        if (!api_row.count(k.queue)) api_row.emplace(k.queue, 50 + (int)api_row.size());
+      } else if (!k.copy && is_collective_name(k.name)) {
+        any_collective = true;
+      } else if (!queue_row.count(k.queue)) {
+        queue_row.emplace(k.queue, 100 + (int)queue_row.size());
+      }
     }
+    for (auto& [t, row] : api_row)
+      o << ",\n{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":" << row
+        << ",\"name\":\"thread_name\",\"args\":{\"name\":\"HIP API calls (host thread " << t << ")\"}}";
     for (auto& [q, row] : queue_row)
       o << ",\n{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":" << row
         << ",\"name\":\"thread_name\",\"args\":{\"name\":\"HIP queue " << (row - 100) << " (id " << q << ")\"}}";
@@ -256,10 +270,17 @@ class RangeTracer {
       o << ",\n{\"ph\":\"M\",\"pid\":" << rank << ",\"tid\":" << kCollectiveRow
         << ",\"name\":\"thread_name\",\"args\":{\"name\":\"collectives (RCCL)\"}}";
     for (auto& k : kernels_done_) {
+      if (k.api) {  // the host side of a launch / copy: same correlation id as the device-side record
+        o << ",\n{\"ph\":\"X\",\"cat\":\"cuda_runtime\",\"name\":\"" << json_escape(k.name) << "\",\"pid\":" << rank
+          << ",\"tid\":" << api_row[k.queue] << ",\"ts\":" << (k.ts_us - base_host_) << ",\"dur\":" << k.dur_us
+          << ",\"args\":{\"correlation\":" << k.correlation << "}}";
+        continue;
+      }
       const bool coll = !k.copy && is_collective_name(k.name);
       o << ",\n{\"ph\":\"X\",\"cat\":\"" << (k.copy ? "gpu_memcpy" : "kernel") << "\",\"name\":\"" << json_escape(k.name)
         << "\",\"pid\":" << rank << ",\"tid\":" << (coll ? kCollectiveRow : queue_row[k.queue]) << ",\"ts\":"
-        << (k.ts_us - base_host_) << ",\"dur\":" << k.dur_us << ",\"args\":{\"queue\":" << k.queue;
+        << (k.ts_us - base_host_) << ",\"dur\":" << k.dur_us << ",\"args\":{\"queue\":" << k.queue
+        << ",\"correlation\":" << k.correlation;
       if (k.copy) o << ",\"bytes\":" << k.bytes;
       o << "}}";
     }
@@ -302,8 +323,8 @@ class RangeTracer {
   struct Kernel {
     std::string name;
     double ts_us = 0, dur_us = 0;  // host clock
-    uint64_t queue = 0, bytes = 0;
-    bool copy = false;
+    uint64_t queue = 0, bytes = 0, correlation = 0;
+    bool copy = false, api = false;  // api: a host-side HIP call (queue = host thread id)
   };
 
   std::map<std::thread::id, int> thread_rows_;
@@ -370,5 +391,6 @@ void bind_tracer(py::module_& m) {
       .def_property_readonly("num_kernels", &RangeTracer::num_kernels)
       .def_property_readonly("collects_kernels", &RangeTracer::collects_kernels);
   m.def("kernel_trace_available", &pda::ktrace::available);
+  m.def("kernel_trace_debug_counts", &pda::ktrace::debug_counts);
   m.def("kernel_trace_unavailable_reason", &pda::ktrace::unavailable_reason);
 }

@@ -16,6 +16,13 @@ assignments/assignment1/train/trainer.py:53-56) — as:
    buffer (gradient sink) and the embedding backward later adds its rows to the same buffer.
 
 fp32 logits (1.65 GB at B=8, T=1024 for GPT-2) are never materialised.
+
+Above ``PDA_LM_HEAD_CHUNK_ROWS`` token rows (default 8192, the reference's micro-batch) the head runs in
+ROW CHUNKS through one reusable logits buffer (<= 0.83 GB for GPT-2's vocabulary instead of 6.6 GB
+at 64 x 1024 tokens): per chunk the logits GEMM, the loss kernel (which leaves the logits gradient
+in place) and — when gradients are wanted — that chunk's two backward GEMMs follow at once, the
+weight gradient accumulating in one fp32 [V, d] buffer. Backward then only applies the incoming
+scalar gradient: to the kept ``dhidden`` and while adding the fp32 weight gradient to its target.
 """
 from __future__ import annotations
 
@@ -26,6 +33,11 @@ from .. import _ext
 from .linear import _grad_target, input_grad_mm, planned_mm
 
 _PAD = 128
+
+
+def _chunk_rows() -> int:
+    import os
+    return max(1024, int(os.environ.get("PDA_LM_HEAD_CHUNK_ROWS", "8192")))
 
 
 def cross_entropy_reference(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = -100):
@@ -121,6 +133,82 @@ class _LMHeadCrossEntropyFn(torch.autograd.Function):
         return dhidden, dweight, None, None
 
 
+class _ChunkedLMHeadCrossEntropyFn(torch.autograd.Function):
+    """The same loss with the vocabulary-wide buffers cut into row chunks (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, targets, ignore_index, need_grad, chunk):
+        ext = _ext.require()
+        V, d = weight.shape
+        h2 = hidden.reshape(-1, d)
+        rows = h2.shape[0]
+        vp = _padded_cols(V)
+        tgt = targets.reshape(-1).contiguous()
+        n_valid = (tgt != ignore_index).sum().clamp_(min=1).to(torch.float32)
+        scale = n_valid.reciprocal().reshape(1)
+        buf = torch.empty(min(chunk, rows), vp, dtype=hidden.dtype, device=hidden.device)
+        loss = torch.zeros((), dtype=torch.float32, device=hidden.device)
+        dhidden = torch.empty_like(h2) if need_grad and hidden.requires_grad else None
+        want_w = need_grad and weight.requires_grad
+        dw = None
+        for lo in range(0, rows, chunk):
+            n = min(chunk, rows - lo)
+            logits_p = buf[:n]
+            hc = h2[lo:lo + n]
+            planned_mm(hc, weight, trans_b=True, out=logits_p[:, :V])
+            loss += ext.cross_entropy_fwd_bwd(logits_p[:, :V], tgt[lo:lo + n], V, scale, ignore_index).sum()
+            if dhidden is not None:  # logits_p now holds the gradient (zero in the padding columns)
+                dhidden[lo:lo + n] = input_grad_mm(logits_p[:, :V], weight, logits_p)
+            if want_w:
+                if _native_lm_head_wgrad_ok(logits_p, hc, V):
+                    if dw is None:
+                        dw = torch.empty(V, d, dtype=torch.float32, device=hidden.device)
+                        ext_wgrad(logits_p, hc, dw, False, V)
+                    else:
+                        ext_wgrad(logits_p, hc, dw, True, V)
+                else:
+                    part = torch.mm(logits_p[:, :V].t(), hc).float()
+                    dw = part if dw is None else dw.add_(part)
+        ctx.save_for_backward(*[t for t in (dhidden, dw) if t is not None])
+        ctx.have = (dhidden is not None, dw is not None)
+        ctx.hidden_shape = hidden.shape
+        ctx.weight = weight  # consulted for .grad / its gradient sink only
+        ctx.grad_sink = getattr(weight, "_pda_grad_sink", None)
+        return loss * scale[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("lm_head_cross_entropy (chunked): backward ran twice; its kept gradients are "
+                               "scaled in place and cannot be reused")
+        ctx.consumed = True
+        kept = list(ctx.saved_tensors)
+        dhidden = kept.pop(0) if ctx.have[0] else None
+        dw = kept.pop(0) if ctx.have[1] else None
+        weight = ctx.weight
+        dweight = None
+        if dhidden is not None and ctx.needs_input_grad[0]:
+            dhidden = dhidden.mul_(dloss.to(dhidden.dtype)).view(ctx.hidden_shape)
+        else:
+            dhidden = None
+        if dw is not None and ctx.needs_input_grad[1]:
+            target = _grad_target(weight, ctx.grad_sink)
+            s = dloss.to(torch.float32)
+            if target is None:
+                dweight = dw.mul_(s).to(weight.dtype)
+            else:
+                out, acc = target
+                if acc and out.dtype == torch.float32:
+                    out.addcmul_(dw, s)
+                elif acc:
+                    out.add_(dw.mul_(s).to(out.dtype))
+                elif out.dtype == torch.float32:
+                    torch.mul(dw, s, out=out)
+                else:
+                    out.copy_(dw.mul_(s))
+        return dhidden, dweight, None, None, None, None
+
+
 def _native_lm_head_wgrad_ok(dlogits_p, h2, V) -> bool:
     import os
     if os.environ.get("PDA_NO_NATIVE_WGRAD") == "1" or dlogits_p.dtype != torch.bfloat16:
@@ -146,5 +234,9 @@ def lm_head_cross_entropy(hidden: torch.Tensor, weight: torch.Tensor, targets: t
                           ignore_index: int = -100) -> torch.Tensor:
     """``cross_entropy(hidden @ weight.T, targets)`` without fp32 / unpadded logits."""
     if _ext.use_hip(hidden):
+        chunk = _chunk_rows()
+        if hidden.numel() // hidden.shape[-1] > chunk:
+            need_grad = torch.is_grad_enabled() and (hidden.requires_grad or weight.requires_grad)
+            return _ChunkedLMHeadCrossEntropyFn.apply(hidden, weight, targets, ignore_index, need_grad, chunk)
         return _LMHeadCrossEntropyFn.apply(hidden, weight, targets, ignore_index)
     return lm_head_cross_entropy_reference(hidden, weight, targets, ignore_index)

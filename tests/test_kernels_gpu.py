@@ -152,6 +152,46 @@ def test_lm_head_cross_entropy(vocab, d):
     assert rel_err(wa.grad, wr.grad) < 2e-2
 
 
+@pytest.mark.parametrize("existing_grad", [None, torch.bfloat16])
+def test_lm_head_cross_entropy_in_row_chunks(monkeypatch, existing_grad):
+    """Above the chunk size the head runs through one reusable logits buffer: same loss and
+    gradients as the one-piece path and as the fp32 reference (V = 50257, ragged last chunk,
+    ignored targets, a scaled loss, and accumulation into an existing weight gradient)."""
+    _ext_loaded()
+    monkeypatch.setenv("PDA_LM_HEAD_CHUNK_ROWS", "1024")
+    torch.manual_seed(15)
+    vocab, d, rows = 50257, 256, 2 * 1024 + 452
+    h = torch.randn(rows, d, device=DEV, dtype=torch.bfloat16)
+    w = (0.05 * torch.randn(vocab, d, device=DEV)).to(torch.bfloat16)
+    targets = torch.randint(0, vocab, (rows,), device=DEV)
+    targets[::11] = -100
+    prior = 0.01 * torch.randn(vocab, d, device=DEV)
+
+    def run(chunked):
+        monkeypatch.setenv("PDA_LM_HEAD_CHUNK_ROWS", "1024" if chunked else "1000000")
+        ha, wa = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if existing_grad is not None:
+            wa.grad = prior.to(existing_grad)
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss = ops.lm_head_cross_entropy(ha, wa, targets)
+        (loss * 0.25).backward()
+        torch.cuda.synchronize()
+        return loss.item(), ha.grad, wa.grad, torch.cuda.max_memory_allocated() - base
+
+    loss_c, dh_c, dw_c, peak_c = run(True)
+    loss_1, dh_1, dw_1, peak_1 = run(False)
+    hr, wr = h.float().requires_grad_(True), w.float().requires_grad_(True)
+    if existing_grad is not None:
+        wr.grad = prior.to(existing_grad).float()
+    loss_ref = ops.lm_head_cross_entropy_reference(hr, wr, targets)
+    (loss_ref * 0.25).backward()
+    assert abs(loss_c - loss_1) < 1e-4 * abs(loss_1) and abs(loss_c - loss_ref.item()) < 5e-3 * abs(loss_ref.item())
+    assert rel_err(dh_c, dh_1) < 1e-3 and rel_err(dh_c, hr.grad) < 2e-2
+    assert rel_err(dw_c, dw_1) < 1e-2 and rel_err(dw_c, wr.grad) < 2e-2
+    assert peak_c < 0.85 * peak_1, (peak_c, peak_1)  # one 1024-row logits buffer instead of 2500 rows
+
+
 # --------------------------------------------------------------------------- AdamW
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_adamw_matches_torch(dtype):
