@@ -32,6 +32,18 @@ from . import comm
 STATE_KEYS = ("exp_avg", "exp_avg_sq")
 
 
+def _settle_optimizer(optimizer, replacing_state: bool = False) -> None:
+    """FusedAdamW keeps its step counts as one integer per group between steps and caches views of its
+    state: bring the per-parameter ``state[p]["step"]`` tensors up to date before they are read, and
+    drop the cached views before state entries are replaced."""
+    if optimizer is None:
+        return
+    if replacing_state and hasattr(optimizer, "_drop_fast"):
+        optimizer._drop_fast()
+    elif hasattr(optimizer, "_catch_up_host_steps"):
+        optimizer._catch_up_host_steps()
+
+
 def _units(model) -> list:
     from .fsdp import FSDP
 
@@ -158,6 +170,7 @@ def _gather_flat(shard: torch.Tensor, unit) -> torch.Tensor:
 def full_optim_state_dict(model, optimizer, cpu_offload: bool = True) -> dict:
     """Optimizer state of a sharded model in ``torch.optim.AdamW`` layout over the bare model's
     parameters. Collective: every rank must call it."""
+    _settle_optimizer(optimizer)
     order = {id(p): i for i, p in enumerate(_ordered_params(model))}
     state = {}
     for u in _units(model):
@@ -182,6 +195,7 @@ def full_optim_state_dict(model, optimizer, cpu_offload: bool = True) -> dict:
 
 def load_full_optim_state_dict(model, optimizer, full_state: dict) -> None:
     """Inverse of :func:`full_optim_state_dict`: slices a full AdamW state into the local shards."""
+    _settle_optimizer(optimizer, replacing_state=True)
     order = {id(p): i for i, p in enumerate(_ordered_params(model))}
     saved = full_state["state"]
     for u in _units(model):
@@ -213,6 +227,7 @@ def load_full_optim_state_dict(model, optimizer, full_state: dict) -> None:
 def save_sharded_checkpoint(directory: str, model, optimizer=None, step: int = 0, lr_scheduler=None) -> str:
     """Writes this rank's shards to ``directory/rank{r}_of_{W}.pt`` (no collective)."""
     os.makedirs(directory, exist_ok=True)
+    _settle_optimizer(optimizer)
     rank, world = comm.get_rank(), comm.get_world_size()
     layouts = unit_layouts(model)
     units = []
@@ -270,6 +285,7 @@ def load_sharded_checkpoint(directory: str, model, optimizer=None, lr_scheduler=
     cuts its new shard ranges out of the saved rank files that overlap them. The unit layout
     (which parameters form a unit, in which order) must be the one that was saved. Returns the
     saved step."""
+    _settle_optimizer(optimizer, replacing_state=True)
     rank, world = comm.get_rank(), comm.get_world_size()
     with open(os.path.join(directory, "meta.json")) as f:
         meta = json.load(f)

@@ -271,6 +271,12 @@ class Trainer:
             print(f"Training completed in {self._elapsed():.1f}s")
 
     def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:
+        # a model wrapped in parallel.GradAccumulator sums the window's micro-batches in its own
+        # buffers and wants to know which backward closes the window
+        no_sync = getattr(self.model, "no_sync", None)
+        if no_sync is not None and not is_last_microbatch:
+            with no_sync():
+                return self.training_step(inputs, targets)
         return self.training_step(inputs, targets)
 
     # ------------------------------------------------------------------ data position

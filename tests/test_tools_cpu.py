@@ -54,3 +54,35 @@ def test_kernel_clock_divides_active_cycles_by_eight_dies_and_duration(tmp_path)
                          check=True, capture_output=True, text=True).stdout
     assert "2.00 GHz" in out and "wgrad_kernel4" in out
     assert "tiny_kernel" not in out  # dispatches under 20 us read high and are not listed
+
+
+def test_analyze_traces_draws_the_notebook_figures(tmp_path):
+    """analyze_traces.py --plots: temporal-breakdown pies and the overlap chart from per-rank traces
+    (kernel rows on the ranges' clock, collectives recognised by name)."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def trace(path, with_comm):
+        ev = [{"ph": "X", "cat": "user_annotation", "name": "ProfilerStep#4", "pid": 0, "tid": 0, "ts": 0.0, "dur": 1000.0}]
+        for i in range(8):
+            ev.append({"ph": "X", "cat": "kernel", "name": "gemm", "pid": 0, "tid": 100, "ts": 100.0 * i, "dur": 80.0})
+        if with_comm:
+            ev.append({"ph": "X", "cat": "kernel", "name": "ncclDevKernel_AllReduce", "pid": 0, "tid": 9000, "ts": 150.0, "dur": 100.0})
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"traceEvents": ev}, f)
+
+    trace(str(tmp_path / "traces" / "baseline" / "trace.json"), False)
+    trace(str(tmp_path / "traces" / "ddp" / "rank0_trace.json"), True)
+    trace(str(tmp_path / "traces" / "ddp" / "rank1_trace.json"), True)
+    out = subprocess.run([sys.executable, os.path.join(root, "analyze_traces.py"), "--traces", str(tmp_path / "traces"),
+                          "--step", "4", "--plots", str(tmp_path / "plots")], capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    assert "ddp" in out.stdout and "overlap" in out.stdout
+    for name in ("temporal_breakdown.png", "comm_comp_overlap.png"):
+        p = tmp_path / "plots" / name
+        assert p.exists() and p.stat().st_size > 5000, name
+    # 100 us of communication (150..250), 30 + 50 of it under the two compute kernels it spans -> 80 % overlap
+    row = [ln for ln in out.stdout.splitlines() if ln.startswith("ddp")][0].split()
+    assert abs(float(row[-1]) - 80.0) < 0.5, row

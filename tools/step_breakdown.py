@@ -1,9 +1,9 @@
 """Per-optimizer-step kernel time by category from a rocprofv3 kernel trace of bench.py.
 
-usage: python tools/step_breakdown.py <kernel_trace.csv> [steps]
-Steps are delimited by the cross-entropy kernel (one launch per micro-batch, one micro-batch per
-step in the default bench); the last `steps` of them are averaged, so planner tuning and warm-up
-launches earlier in the trace do not count.
+usage: python tools/step_breakdown.py <kernel_trace.csv> [steps] [micro_batches_per_step]
+Micro-batches are delimited by the cross-entropy kernel (one launch per micro-batch; one micro-batch
+per step in the default bench, four in the reference's recipe); the last `steps` optimizer steps are
+averaged, so planner tuning and warm-up launches earlier in the trace do not count.
 """
 import collections
 import csv
@@ -24,10 +24,11 @@ def category(n: str) -> str:
 
 def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     marks = [i for i, r in enumerate(rows) if "::ce_kernel" in r["Kernel_Name"]]
-    lo, hi = marks[-steps - 1], marks[-1]
+    lo, hi = marks[-steps * per - 1], marks[-1]
     sel = rows[lo:hi]
     wall = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e6 / steps
     tot, cnt = collections.Counter(), collections.Counter()
