@@ -24,7 +24,7 @@ CONFIGS = ["baseline", "ddp", "fsdp_full_shard", "fsdp_shard_grad_op", "fsdp_no_
 
 
 def _rank0_trace(trace_root, cfg):
-    for name in ("rank0_trace.json", "trace.json"):
+    for name in ("rank0_trace.json", "trace.json", "rank0_trace.json.gz", "trace.json.gz"):
         p = os.path.join(trace_root, cfg, name)
         if os.path.exists(p):
             return p

@@ -198,6 +198,7 @@ def main():
     from pytorch_distributed_amd import MI355X_PEAK_BF16_FLOPS
     from pytorch_distributed_amd.data import SyntheticTokenLoader
     from pytorch_distributed_amd.models import LlamaForCausalLM, MyGPT2LMHeadModel, get_config, init_on_device
+    from pytorch_distributed_amd.ops.linear import accumulation_window
     from pytorch_distributed_amd.optim import FusedAdamW
     from pytorch_distributed_amd.parallel import autotune, comm
     from pytorch_distributed_amd.utils.flops import model_flops_per_token
@@ -295,11 +296,14 @@ def main():
         def one_step():
             for i in range(accum):
                 inputs, targets = next(loader)
-                if distributed and i < accum - 1:
-                    with model.no_sync():
+                # gradients are read only after the last micro-batch: the linear layers form each weight
+                # gradient once, over the whole window (ops.linear.accumulation_window)
+                with accumulation_window(i, accum):
+                    if distributed and i < accum - 1:
+                        with model.no_sync():
+                            (model(inputs, targets) / accum).backward()
+                    else:
                         (model(inputs, targets) / accum).backward()
-                else:
-                    (model(inputs, targets) / accum).backward()
             optimizer.step(zero_grad=True)
 
         if args.hip_graph:

@@ -414,6 +414,14 @@ at::Tensor rope_apply(const at::Tensor& qkv, const at::Tensor& cos, const at::Te
 // ---------------------------------------------------------------- weight grad --
 bool wgrad_supported(int64_t M, int64_t I, int64_t J) { return pda::wgrad_supported((int)M, (int)I, (int)J); }
 
+// Can `n` pairs of `rows` rows each go through linear_wgrad_segments?
+bool wgrad_segments_supported(int64_t rows, int64_t I, int64_t J, int64_t n) {
+  if (n < 1 || n > pda::wgrad_max_segments() || rows < 32 || rows % 32 != 0) return false;
+  const int64_t steps = rows / 32;
+  if ((steps & (steps - 1)) != 0 || rows * n >= (int64_t(1) << 31)) return false;
+  return pda::wgrad_supported((int)(rows * n), (int)I, (int)J);
+}
+
 // dW[I, J] = dy[M, I]^T . x[M, J] and (optionally) db[I] = column sums of dy, both bf16.
 // With `out` the weight gradient is written into that tensor (a slice of a reducer's flat
 // gradient buffer) instead of a fresh one — added to its contents when `accumulate` is set.
@@ -468,6 +476,79 @@ std::vector<at::Tensor> linear_wgrad(const at::Tensor& dy, const at::Tensor& x, 
     }
   }
   pda::wgrad_reduce(partial.data_ptr<float>(), S, out_rows * J, I * J, dtype_of(dw), dw.data_ptr(), accumulate,
+                    want_bias ? bpartial.data_ptr<float>() : nullptr, I, want_bias ? dtype_of(db) : pda::kBF16,
+                    want_bias ? db.data_ptr() : nullptr, want_bias && bias_accumulate, stream);
+  check_launch("wgrad_reduce");
+  return {dw, db};
+}
+
+// The same product over the row-wise concatenation of up to wgrad_max_segments() (dy, x) pairs that
+// live in separate buffers (the micro-batches of a gradient-accumulation window): ONE long-K GEMM and
+// one slice reduction instead of one of each per micro-batch. Every pair has the same shape and row
+// strides; rows per pair / 32 must be a power of two (the kernel finds a stage's pair with a shift).
+std::vector<at::Tensor> linear_wgrad_segments(const std::vector<at::Tensor>& dys, const std::vector<at::Tensor>& xs,
+                                              bool want_bias, const std::optional<at::Tensor>& out, bool accumulate,
+                                              const std::optional<at::Tensor>& bias_out, bool bias_accumulate) {
+  const int64_t n = (int64_t)dys.size();
+  TORCH_CHECK(n >= 1 && n <= pda::wgrad_max_segments() && (int64_t)xs.size() == n, "wgrad segments: need 1..",
+              pda::wgrad_max_segments(), " (dy, x) pairs, got ", n, " and ", xs.size());
+  if (n == 1) return linear_wgrad(dys[0], xs[0], want_bias, out, accumulate, bias_out, bias_accumulate, -1);
+  const at::Tensor& dy0 = dys[0];
+  const at::Tensor& x0 = xs[0];
+  TORCH_CHECK(dy0.is_cuda() && dy0.dim() == 2 && x0.dim() == 2, "wgrad segments: 2-D GPU tensors");
+  const int64_t rows = dy0.size(0), I = dy0.size(1), J = x0.size(1);
+  TORCH_CHECK(wgrad_segments_supported(rows, I, J, n), "wgrad segments: unsupported shape ", n, "x", rows, "x", I, "x", J);
+  const void* a[4];
+  const void* b[4];
+  for (int64_t k = 0; k < n; ++k) {
+    const at::Tensor& dy = dys[k];
+    const at::Tensor& x = xs[k];
+    TORCH_CHECK(dy.is_cuda() && x.is_cuda() && dy.device() == dy0.device() && x.device() == dy0.device() &&
+                    dy.scalar_type() == at::kBFloat16 && x.scalar_type() == at::kBFloat16,
+                "wgrad segments: bf16 tensors on one GPU");
+    TORCH_CHECK(dy.dim() == 2 && x.dim() == 2 && dy.size(0) == rows && x.size(0) == rows && dy.size(1) == I &&
+                    x.size(1) == J && dy.stride(1) == 1 && x.stride(1) == 1 && dy.stride(0) == dy0.stride(0) &&
+                    x.stride(0) == x0.stride(0),
+                "wgrad segments: pair ", k, " differs in shape or strides from pair 0");
+    TORCH_CHECK(dy.stride(0) % 8 == 0 && x.stride(0) % 8 == 0 && reinterpret_cast<uintptr_t>(dy.data_ptr()) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0,
+                "wgrad segments: operands must be 16-byte aligned with row strides that are multiples of 8");
+    a[k] = dy.data_ptr();
+    b[k] = x.data_ptr();
+  }
+  const c10::DeviceGuard guard(dy0.device());
+  const int64_t M = rows * n;
+  const int S = pda::wgrad_pick_slices((int)M, (int)I, (int)J);
+  auto f32 = dy0.options().dtype(at::kFloat);
+  at::Tensor partial = at::empty({S, I, J}, f32);
+  at::Tensor bpartial = want_bias ? at::empty({S, I}, f32) : at::Tensor();
+  hipStream_t stream = current_stream();
+  pda::wgrad_gemm_segments(a, dy0.stride(0), b, x0.stride(0), (int)n, partial.data_ptr<float>(),
+                           want_bias ? bpartial.data_ptr<float>() : nullptr, (int)rows, (int)I, (int)J, S, stream);
+  check_launch("wgrad_gemm_segments");
+  at::Tensor dw;
+  if (out.has_value()) {
+    dw = *out;
+    TORCH_CHECK(dw.is_cuda() && dw.is_contiguous() && dw.numel() == I * J &&
+                    (dw.scalar_type() == at::kBFloat16 || dw.scalar_type() == at::kFloat),
+                "wgrad segments: out must be a contiguous bf16/fp32 GPU tensor with ", I * J, " elements");
+  } else {
+    TORCH_CHECK(!accumulate, "wgrad segments: accumulate needs an out tensor");
+    dw = at::empty({I, J}, dy0.options());
+  }
+  at::Tensor db;
+  if (want_bias) {
+    if (bias_out.has_value() && bias_out->defined()) {
+      db = *bias_out;
+      TORCH_CHECK(db.is_cuda() && db.is_contiguous() && db.numel() == I &&
+                      (db.scalar_type() == at::kBFloat16 || db.scalar_type() == at::kFloat),
+                  "wgrad segments: bias_out must be a contiguous bf16/fp32 GPU tensor with ", I, " elements");
+    } else {
+      TORCH_CHECK(!bias_accumulate, "wgrad segments: bias_accumulate needs a bias_out tensor");
+      db = at::empty({I}, dy0.options());
+    }
+  }
+  pda::wgrad_reduce(partial.data_ptr<float>(), S, I * J, I * J, dtype_of(dw), dw.data_ptr(), accumulate,
                     want_bias ? bpartial.data_ptr<float>() : nullptr, I, want_bias ? dtype_of(db) : pda::kBF16,
                     want_bias ? db.data_ptr() : nullptr, want_bias && bias_accumulate, stream);
   check_launch("wgrad_reduce");
@@ -622,6 +703,11 @@ void bind_ops(py::module_& m) {
   m.def("linear_wgrad", &linear_wgrad, py::arg("dy"), py::arg("x"), py::arg("want_bias"),
         py::arg("out") = py::none(), py::arg("accumulate") = false, py::arg("bias_out") = py::none(),
         py::arg("bias_accumulate") = false, py::arg("out_rows") = -1);
+  m.def("wgrad_segments_supported", &wgrad_segments_supported, py::arg("rows"), py::arg("I"), py::arg("J"), py::arg("n"));
+  m.def("wgrad_max_segments", []() { return pda::wgrad_max_segments(); });
+  m.def("linear_wgrad_segments", &linear_wgrad_segments, py::arg("dys"), py::arg("xs"), py::arg("want_bias"),
+        py::arg("out") = py::none(), py::arg("accumulate") = false, py::arg("bias_out") = py::none(),
+        py::arg("bias_accumulate") = false);
   m.def("norm_forward", &norm_forward, py::arg("x"), py::arg("residual"), py::arg("weight"),
         py::arg("bias"), py::arg("eps"), py::arg("rms"), py::arg("dropout_p") = 0.0, py::arg("seed") = 0);
   m.def("norm_backward", &norm_backward, py::arg("dy"), py::arg("x"), py::arg("weight"), py::arg("mean"),

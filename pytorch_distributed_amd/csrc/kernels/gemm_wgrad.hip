@@ -355,12 +355,26 @@ __device__ unsigned long long g_wgrad_stamps[1024 * 4 * 8];  // [workgroup][wave
 #define PDA_STAMP(var)
 #endif
 
-template <int kUnused>
+// Segmented operands (kSegmented = 1): the M rows are the concatenation of up to kMaxSegments equally
+// long pieces that live at unrelated addresses — the (dY, X) pairs of the micro-batches of a gradient
+// accumulation window, whose weight gradient is then ONE long-K product instead of one short product
+// plus one slice reduction per micro-batch. Slices may span pieces: the piece and the row of a stage
+// follow from its index by a shift and a mask (a piece holds a power-of-two number of stages), and
+// the per-lane source pointers are taken relative to piece 0 plus the piece's wave-uniform address
+// difference. No state is carried from stage to stage: the stage body stays branch-free.
+constexpr int kMaxSegments = 4;
+struct WgradSegments {  // plain scalars: an array member would be indexed through scratch memory
+  const bf16_raw *a1, *a2, *a3, *b1, *b2, *b3;  // pieces 1..3 (piece 0 is the kernel's A / B)
+  int n;          // pieces in use
+  int log2_steps;  // log2 of the pipeline stages (kBM rows each) per piece
+};
+
+template <int kSegmented>
 __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __restrict__ A, int64_t lda,
                                                            const bf16_raw* __restrict__ B, int64_t ldb,
                                                            float* __restrict__ c_partial,
                                                            float* __restrict__ bias_partial, int M, int I,
-                                                           int J, int S, int i_fast) {
+                                                           int J, int S, int i_fast, WgradSegments segs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PDA_WGRAD_STAMPS
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
@@ -418,14 +432,44 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
   // The four roles of a wave differ by 8 q + 16 half rows, a multiple of 4: the swizzle (row & 3) and
   // with it the per-lane column are the same for all of them, so ONE per-lane pointer per operand
   // serves every load and the rest of the address is wave-uniform.
-  const bf16_raw* a_src = stage_src(A, lda, step_lo * kBM, ti * kTile, I, 0, wave, lane);
-  const bf16_raw* b_src = stage_src(B, ldb, step_lo * kBM, tj * kTile, J, 0, wave, lane);
+  const bf16_raw* a_src = stage_src(A, lda, kSegmented ? 0 : step_lo * kBM, ti * kTile, I, 0, wave, lane);
+  const bf16_raw* b_src = stage_src(B, ldb, kSegmented ? 0 : step_lo * kBM, tj * kTile, J, 0, wave, lane);
   const int64_t a_stride = int64_t(kBM) * lda, b_stride = int64_t(kBM) * ldb;
+  // Segmented operands: wave-uniform element differences of pieces 1..3 against piece 0.
+  // (Locals, so that no lambda below captures the argument struct itself: a captured struct has its
+  // address taken, is copied to scratch memory, and drags the loop's scalars into vector registers.)
+  int64_t a_d1 = 0, a_d2 = 0, a_d3 = 0, b_d1 = 0, b_d2 = 0, b_d3 = 0;
+  const int seg_log2 = kSegmented ? segs.log2_steps : 0;
+  if (kSegmented) {
+    a_d1 = int64_t(segs.a1 - A), a_d2 = int64_t(segs.a2 - A), a_d3 = int64_t(segs.a3 - A);
+    b_d1 = int64_t(segs.b1 - B), b_d2 = int64_t(segs.b2 - B), b_d3 = int64_t(segs.b3 - B);
+  }
   // Load `i` (0..7) of stage t into ring slot `slot_idx`; issue order = age order:
   // A rows 0-15 (2 loads), B rows 0-15 (2), A rows 16-31 (2), B rows 16-31 (2).
   auto issue_one = [&](int t, int slot_idx, int i) {
     char* slot = smem + slot_idx * kStageBytes;
     const int half = i >> 2, is_b = (i >> 1) & 1, q = i & 1;
+    if (kSegmented) {
+      const int g = step_lo + (t < n_steps ? t : n_steps - 1);  // stage index over all pieces, wave-uniform
+      const int piece = g >> seg_log2, local = g & ((1 << seg_log2) - 1);
+      const int64_t rows = int64_t(local) * kBM + 16 * half + 8 * q;
+      // Selects between VALUES (copied first): `c ? b_d3 : b_d2` on the by-reference captures themselves
+      // is a select between two addresses followed by a load, which pins every captured local in
+      // scratch memory and drags the loop's scalars into vector registers.
+      const bool lo = (piece & 1) != 0, hi = (piece & 2) != 0;
+      if (is_b) {
+        const int64_t d1 = b_d1, d2 = b_d2, d3 = b_d3;
+        const int64_t d_hi = lo ? d3 : d2, d_lo = lo ? d1 : int64_t(0);
+        const int64_t d = hi ? d_hi : d_lo;
+        stage_half(b_src + d + rows * ldb, slot + kTileBytes, half, wave + 4 * q);
+      } else {
+        const int64_t d1 = a_d1, d2 = a_d2, d3 = a_d3;
+        const int64_t d_hi = lo ? d3 : d2, d_lo = lo ? d1 : int64_t(0);
+        const int64_t d = hi ? d_hi : d_lo;
+        stage_half(a_src + d + rows * lda, slot, half, wave + 4 * q);
+      }
+      return;
+    }
     const int64_t rows = int64_t(t < n_steps ? t : n_steps - 1) * kBM + 16 * half + 8 * q;  // wave-uniform
     if (is_b) stage_half(b_src + rows * ldb, slot + kTileBytes, half, wave + 4 * q);
     else stage_half(a_src + rows * lda, slot, half, wave + 4 * q);
@@ -483,7 +527,6 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
         __builtin_amdgcn_sched_barrier(0);
         PDA_STAMP(ts1);
         const unsigned a_tile = smem_base + u * kStageBytes;
-
         // ---- k-step 0: 16 MFMAs; in their shadow the 16 fragment reads of k-step 1 (two after
         // each of the first eight), then the 8 global loads that refill the slot the barrier freed.
         bf16x8 af[4], bfr[4];
@@ -962,12 +1005,35 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
     const int tiles_i = (I + kTile - 1) / kTile, tiles_j = (J + kTile - 1) / kTile;
     const int i_fast = order < 0 ? (tiles_j > tiles_i) : order;
     hipLaunchKernelGGL(wgrad_kernel4<0>, dim3((unsigned)n_tasks), dim3(kThreads4), kStages * kStageBytes, stream,
-                       (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S, i_fast);
+                       (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S, i_fast,
+                       WgradSegments{});
     return;
   }
   auto kern = mode == 1 ? wgrad_kernel<1> : mode == 2 ? wgrad_kernel<2> : wgrad_kernel<0>;
   hipLaunchKernelGGL(kern, dim3((unsigned)n_tasks), dim3(kThreads), kStages * kStageBytes, stream,
                      (const bf16_raw*)A, lda, (const bf16_raw*)B, ldb, c_partial, bias_partial, M, I, J, S);
+}
+
+int wgrad_max_segments() { return kMaxSegments; }
+
+void wgrad_gemm_segments(const void* const* A, int64_t lda, const void* const* B, int64_t ldb, int n_segments,
+                         float* c_partial, float* bias_partial, int rows_per_segment, int I, int J, int S,
+                         hipStream_t stream) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel4<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStages * kStageBytes);
+    configured = true;
+  }
+  auto piece = [&](const void* const* p, int k) { return (const bf16_raw*)p[k < n_segments ? k : 0]; };
+  int log2_steps = 0;
+  while ((1 << log2_steps) < rows_per_segment / kBM) ++log2_steps;
+  WgradSegments segs{piece(A, 1), piece(A, 2), piece(A, 3), piece(B, 1), piece(B, 2), piece(B, 3), n_segments,
+                     log2_steps};
+  const int tiles_i = (I + kTile - 1) / kTile, tiles_j = (J + kTile - 1) / kTile;
+  const int n_tasks = tiles_i * tiles_j * S;
+  hipLaunchKernelGGL(wgrad_kernel4<1>, dim3((unsigned)n_tasks), dim3(kThreads4), kStages * kStageBytes, stream,
+                     piece(A, 0), lda, piece(B, 0), ldb, c_partial, bias_partial, rows_per_segment * n_segments, I, J, S,
+                     int(tiles_j > tiles_i), segs);
 }
 
 void wgrad_reduce(const float* partial, int S, int64_t numel, int64_t slice_stride, DType out_dtype, void* out, bool accumulate,

@@ -129,6 +129,13 @@ void wgrad_gemm(const void* A, int64_t lda, const void* B, int64_t ldb, float* c
 // Folds the first `numel` elements of every slice (slices `slice_stride` elements apart; numel ==
 // slice_stride for a whole result, smaller when only the leading rows of C are wanted).
 // bias_partial (optional, [S][bias_numel]) is folded into bias_out (bf16) by the same launch.
+// The same product over rows that are the concatenation of `n_segments` (<= wgrad_max_segments())
+// equally long pieces at unrelated addresses: A[k] is [rows_per_segment, I], B[k] [rows_per_segment, J],
+// all with the row pitches lda / ldb. One long-K GEMM for the (dY, X) pairs of several micro-batches.
+int wgrad_max_segments();
+void wgrad_gemm_segments(const void* const* A, int64_t lda, const void* const* B, int64_t ldb, int n_segments,
+                         float* c_partial, float* bias_partial, int rows_per_segment, int I, int J, int S,
+                         hipStream_t stream);
 void wgrad_reduce(const float* partial, int S, int64_t numel, int64_t slice_stride, DType out_dtype, void* out, bool accumulate,
                   const float* bias_partial, int64_t bias_numel, DType bias_dtype, void* bias_out,
                   bool bias_accumulate, hipStream_t stream);

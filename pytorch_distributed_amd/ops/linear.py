@@ -26,9 +26,21 @@ that are not multiples of 8, token counts that are not multiples of 32) fall to 
 inside the same function, and CPU tensors use ``torch`` matmuls.
 ``PDA_NO_NATIVE_WGRAD=1`` / ``PDA_NO_GEMM_PLANNER=1`` switch the two native paths off
 (A/B measurements).
+
+Gradient accumulation (``accumulation_window``): the weight gradient of a window of micro-batches
+is the product over the CONCATENATION of their tokens, so inside a declared window the
+``(dY, X)`` pairs of all but the last micro-batch are kept instead of multiplied, and the last
+micro-batch's backward runs ONE long-K GEMM per weight over all of them
+(``linear_wgrad_segments``: the kernel reads up to four separate buffers as one operand). That
+replaces N short split-K GEMMs + N slice reductions + N read-modify-writes of the gradient by one
+of each, accumulates the whole window in fp32, and leaves the non-final backward passes with only
+their input-gradient GEMMs. The kept operands cost memory (about 0.33 GB per GPT-2-large block per
+micro-batch of 8 x 1024 tokens), so keeping stops at a budget taken from the memory that is free
+at the first backward of the window; ``PDA_DEFER_WGRAD=0`` switches it off.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -153,6 +165,111 @@ def _grad_target(param, sink, wide_ok: bool = True):
     return target
 
 
+class _Window:
+    """State of the gradient-accumulation window whose backward passes are running."""
+    __slots__ = ("index", "total", "kept", "kept_bytes", "budget")
+
+    def __init__(self):
+        self.index, self.total = 0, 1
+        self.kept: dict = {}  # id(weight) -> (weight, [(dy2, x2), ...])
+        self.kept_bytes = 0   # of the micro-batch `index`
+        self.budget = None    # bytes one micro-batch may keep; measured at the window's first keep
+
+    def clear(self):
+        self.kept.clear()
+        self.kept_bytes = 0
+        self.budget = None
+
+
+_WINDOW = _Window()
+_ACTIVE = False  # inside accumulation_window()
+
+
+def deferred_weight_grads_enabled() -> bool:
+    return os.environ.get("PDA_DEFER_WGRAD", "1") != "0"
+
+
+@contextlib.contextmanager
+def accumulation_window(index: int, total: int):
+    """Declares that the backward passes run inside belong to micro-batch ``index`` of a window of
+    ``total`` micro-batches whose gradients are summed before the optimizer step, and that nobody
+    reads the weight gradients before the window's last backward has run (no gradient
+    synchronisation in between: the caller is inside ``no_sync()``, or the model is not wrapped).
+    The last micro-batch (``index == total - 1``) computes every kept product."""
+    global _ACTIVE
+    w = _WINDOW
+    if total < 2 or _ACTIVE or not deferred_weight_grads_enabled():
+        yield
+        return
+    if index == 0 or index != w.index + 1 or total != w.total:
+        w.clear()  # a new window (or an abandoned one: its operands are dropped, like its gradients)
+    w.index, w.total, w.kept_bytes = index, total, 0
+    _ACTIVE = True
+    try:
+        yield
+    except BaseException:
+        _ACTIVE = False
+        w.clear()
+        raise
+    _ACTIVE = False
+    if index == total - 1:
+        left = len(w.kept)
+        w.clear()
+        if left:  # a layer that ran in an earlier micro-batch but not in the last one: its products were never formed
+            raise RuntimeError(f"accumulation_window: {left} weight(s) had operands kept from earlier micro-batches "
+                               "but took no part in the last micro-batch's backward; their gradients would be "
+                               "lost. Set PDA_DEFER_WGRAD=0 for models whose layers run conditionally.")
+
+
+def pending_weight_grads() -> int:
+    """Number of weights with kept operands (0 outside a window and after its last backward)."""
+    return len(_WINDOW.kept)
+
+
+def _keep_for_later(dy2, x2, weight) -> bool:
+    """Keeps one (dY, X) pair for the window's last backward; False when the budget is used up."""
+    w = _WINDOW
+    if w.budget is None:
+        free, _ = torch.cuda.mem_get_info(dy2.device)
+        cached = torch.cuda.memory_reserved(dy2.device) - torch.cuda.memory_allocated(dy2.device)
+        # Measured where a backward starts, i.e. at the activation peak: what is free now is what the
+        # later micro-batches' kept operands can grow into.
+        w.budget = int(0.8 * (free + cached)) // max(1, w.total - 1)
+    size = dy2.numel() * dy2.element_size() + x2.numel() * x2.element_size()
+    if w.kept_bytes + size > w.budget:
+        return False
+    w.kept_bytes += size
+    entry = w.kept.get(id(weight))
+    if entry is None:
+        entry = w.kept[id(weight)] = (weight, [])
+    entry[1].append((dy2, x2))
+    return True
+
+
+def _wgrad_over_pairs(pairs, need_b, w_out, w_acc, b_out, b_acc):
+    """One kernel call per run of up to ``wgrad_max_segments()`` equally shaped pairs."""
+    ext = _ext.require()
+    cap = ext.wgrad_max_segments()
+    dw = db = None
+    i = 0
+    while i < len(pairs):
+        dy0, x0 = pairs[i]
+        n = 1
+        while (i + n < len(pairs) and n < cap and pairs[i + n][0].shape == dy0.shape
+               and pairs[i + n][1].shape == x0.shape):
+            n += 1
+        while n > 1 and not ext.wgrad_segments_supported(dy0.shape[0], dy0.shape[1], x0.shape[1], n):
+            n -= 1
+        chunk = pairs[i:i + n]
+        dw, db = ext.linear_wgrad_segments([p[0] for p in chunk], [p[1] for p in chunk], bool(need_b),
+                                           w_out, w_acc, b_out, b_acc)
+        w_out, w_acc = dw, True
+        if need_b:
+            b_out, b_acc = db, True
+        i += n
+    return dw, db
+
+
 def weight_grads(dy2, x2, weight, bias, grad_sink, bias_sink, need_w: bool, need_b: bool):
     """``(dW, db)`` of ``y = x W^T + b`` from ``dy2 [tokens, out]`` and ``x2 [tokens, in]``.
 
@@ -165,12 +282,24 @@ def weight_grads(dy2, x2, weight, bias, grad_sink, bias_sink, need_w: bool, need
     if need_w and _native_wgrad_ok(dy2, x2):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        x2 = x2.contiguous()
+        pairs = None
+        if _ACTIVE:
+            if _WINDOW.index < _WINDOW.total - 1:
+                if _keep_for_later(dy2, x2, weight):
+                    return None, None  # autograd's accumulator nodes still run (see above)
+            else:
+                entry = _WINDOW.kept.pop(id(weight), None)
+                if entry is not None:
+                    pairs = entry[1] + [(dy2, x2)]
         w_target = _grad_target(weight, grad_sink)
         b_target = _grad_target(bias, bias_sink) if need_b else None
         w_out, w_acc = w_target if w_target is not None else (None, False)
         b_out, b_acc = b_target if b_target is not None else (None, False)
-        dw_native, db_native = _ext.require().linear_wgrad(dy2, x2.contiguous(), bool(need_b), w_out, w_acc,
-                                                           b_out, b_acc)
+        if pairs is not None:
+            dw_native, db_native = _wgrad_over_pairs(pairs, need_b, w_out, w_acc, b_out, b_acc)
+        else:
+            dw_native, db_native = _ext.require().linear_wgrad(dy2, x2, bool(need_b), w_out, w_acc, b_out, b_acc)
         dw = dw_native if w_target is None else None
         if need_b and b_target is None:
             db = db_native

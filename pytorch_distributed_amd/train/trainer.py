@@ -273,11 +273,16 @@ class Trainer:
     def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:
         # a model wrapped in parallel.GradAccumulator sums the window's micro-batches in its own
         # buffers and wants to know which backward closes the window
+        # Nobody reads a gradient before the window's last backward (no_sync in between), so the linear
+        # layers may keep the earlier micro-batches' operands and form each weight gradient once, as one
+        # long product over the whole window (ops.linear.accumulation_window).
+        accum = self.grad_accumulation_steps
         no_sync = getattr(self.model, "no_sync", None)
-        if no_sync is not None and not is_last_microbatch:
-            with no_sync():
-                return self.training_step(inputs, targets)
-        return self.training_step(inputs, targets)
+        with ops.accumulation_window(self.batch_count % accum, accum):
+            if no_sync is not None and not is_last_microbatch:
+                with no_sync():
+                    return self.training_step(inputs, targets)
+            return self.training_step(inputs, targets)
 
     # ------------------------------------------------------------------ data position
     def _data_state(self) -> dict:

@@ -261,3 +261,97 @@ def test_in_process_kernel_trace(tmp_path):
     # nothing from the wait / warm-up steps was collected
     first = min(k["ts"] for k in kernels)
     assert first >= ta.step_window(ev, 2)[0] - 2000, (first, ta.step_window(ev, 2))
+
+
+@pytest.mark.parametrize("wrapper,accum", [("plain", 4), ("plain", 3), ("plain", 6), ("ddp", 4), ("ddp_fp32", 4),
+                                           ("fsdp", 4), ("fsdp_grad_op", 2)])
+def test_weight_gradients_deferred_over_the_accumulation_window(pg, wrapper, accum, monkeypatch):
+    """Inside ops.linear.accumulation_window the (dY, X) pairs of the earlier micro-batches are kept and
+    the last backward forms each weight gradient as one product over the whole window: same training
+    as per-micro-batch products (PDA_DEFER_WGRAD=0), nothing left pending, fewer kernel launches."""
+    from pytorch_distributed_amd import ops as linear_ops
+    from pytorch_distributed_amd.optim import FusedAdamW
+    from pytorch_distributed_amd.parallel import DDP, ShardingStrategy, fsdp_wrap_gpt
+
+    def build():
+        model, cfg = _model(7)
+        if wrapper.startswith("ddp"):
+            model = DDP(model, device_ids=[0], bucket_cap_mb=8, first_bucket_mb=1, force_collectives=True,
+                        grad_accum_dtype="fp32" if wrapper == "ddp_fp32" else "param")
+        elif wrapper.startswith("fsdp"):
+            strategy = ShardingStrategy.SHARD_GRAD_OP if wrapper == "fsdp_grad_op" else ShardingStrategy.FULL_SHARD
+            model = fsdp_wrap_gpt(model, strategy, force_collectives=True)
+        return model, cfg
+
+    def run(defer: bool):
+        monkeypatch.setenv("PDA_DEFER_WGRAD", "1" if defer else "0")
+        model, cfg = build()
+        ids = _ids(cfg, 2 * accum, seed=7)
+        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+        no_sync = getattr(model, "no_sync", None)
+        losses, pending = [], []
+        for step in range(2):
+            for a in range(accum):
+                x = ids[step * accum + a]
+                with linear_ops.accumulation_window(a, accum):
+                    if no_sync is not None and a < accum - 1:
+                        with no_sync():
+                            loss = model(x[:, :-1], x[:, 1:]) / accum
+                            loss.backward()
+                    else:
+                        loss = model(x[:, :-1], x[:, 1:]) / accum
+                        loss.backward()
+                pending.append(linear_ops.pending_weight_grads())
+                losses.append(loss.item() * accum)
+            opt.step(zero_grad=True)
+        torch.cuda.synchronize()
+        sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+        return losses, pending, sd
+
+    losses_d, pending_d, sd_d = run(True)
+    losses_p, pending_p, sd_p = run(False)
+    n_linear = 3 * 4  # c_attn, attn c_proj, c_fc, mlp c_proj in each of 3 blocks
+    assert pending_p == [0] * (2 * accum)
+    assert pending_d == ([n_linear] * (accum - 1) + [0]) * 2, pending_d
+    assert max(abs(a - b) for a, b in zip(losses_d, losses_p)) < 2e-2, (losses_d, losses_p)
+    for k in sd_p:
+        assert (sd_d[k] - sd_p[k]).abs().max().item() < 1e-2, k
+
+
+def test_deferred_weight_gradients_are_closer_to_fp32_than_bf16_accumulation(monkeypatch):
+    """The window's single product accumulates in fp32: its bf16 result is nearer to the exact sum than
+    four bf16 read-modify-writes of .grad; a window abandoned half way leaves nothing behind."""
+    from pytorch_distributed_amd import ops
+    linear_ops = ops
+
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(512, 384, device=DEV, dtype=torch.bfloat16)
+    xs = [torch.randn(4, 256, 512, device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+    gs = [torch.randn(4, 256, 384, device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+    exact_w = sum(g.flatten(0, 1).float().t() @ x.flatten(0, 1).float() for g, x in zip(gs, xs))
+    exact_b = sum(g.flatten(0, 1).float().sum(0) for g in gs)
+
+    def window(defer):
+        monkeypatch.setenv("PDA_DEFER_WGRAD", "1" if defer else "0")
+        lin.weight.grad = lin.bias.grad = None
+        for i, (x, g) in enumerate(zip(xs, gs)):
+            with linear_ops.accumulation_window(i, 4):
+                ops.linear(x, lin.weight, lin.bias).backward(g)
+            if defer and i < 3:
+                assert lin.weight.grad is None and lin.bias.grad is None  # nothing formed yet
+        ew = ((lin.weight.grad.float() - exact_w).norm() / exact_w.norm()).item()
+        eb = ((lin.bias.grad.float() - exact_b).norm() / exact_b.norm()).item()
+        return ew, eb
+
+    ew_d, eb_d = window(True)
+    ew_p, eb_p = window(False)
+    assert ew_d < 3e-3 and eb_d < 3e-3, (ew_d, eb_d)
+    assert ew_d < 0.8 * ew_p, (ew_d, ew_p)
+    # abandoned window: the next window starting at 0 drops the kept operands
+    monkeypatch.setenv("PDA_DEFER_WGRAD", "1")
+    with linear_ops.accumulation_window(0, 4):
+        ops.linear(xs[0], lin.weight, lin.bias).backward(gs[0])
+    assert linear_ops.pending_weight_grads() == 1
+    with linear_ops.accumulation_window(0, 2):
+        pass
+    assert linear_ops.pending_weight_grads() == 0
