@@ -177,7 +177,7 @@ def main():
     target = os.path.abspath(args.target)
     targs = args.target_args
     if not targs and os.path.basename(target) == "bench.py":
-        targs = ["--steps", "2", "--warmup", "2"]
+        targs = ["--steps", "2", "--warmup", "2", "--no-reference-recipe"]
     marker = args.window_kernel
     if marker is None:
         marker = "adamw" if os.path.basename(target) == "bench.py" else ""

@@ -126,7 +126,19 @@ def input_grad_mm(dy2: torch.Tensor, weight: torch.Tensor, dy_padded: torch.Tens
     if pad_to % 8 != 0 or a.shape[0] != M or a.shape[1] != -(-N // pad_to) * pad_to or not _planner_ok(a):
         return direct()
     ext = _ext.require()
-    transposed = lambda: planned_mm(a, ext.transpose_2d(weight, pad_to), trans_b=True)  # noqa: E731
+
+    def weight_t():
+        # The weights do not change inside an accumulation window: micro-batches after the first reuse
+        # the transposed copy (values, not storage: a re-gathered sharded weight holds the same numbers).
+        if not _ACTIVE:
+            return ext.transpose_2d(weight, pad_to)
+        key = (id(weight), pad_to)
+        hit = _WINDOW.transposed.get(key)
+        if hit is None or hit[0] is not weight:
+            hit = _WINDOW.transposed[key] = (weight, ext.transpose_2d(weight, pad_to))
+        return hit[1]
+
+    transposed = lambda: planned_mm(a, weight_t(), trans_b=True)  # noqa: E731
     routes = (direct, transposed)
     key = (weight.device.index, M, N, K)
     choice = _DGRAD_TRANSPOSED.get(key)
@@ -167,16 +179,18 @@ def _grad_target(param, sink, wide_ok: bool = True):
 
 class _Window:
     """State of the gradient-accumulation window whose backward passes are running."""
-    __slots__ = ("index", "total", "kept", "kept_bytes", "budget")
+    __slots__ = ("index", "total", "kept", "kept_bytes", "budget", "transposed")
 
     def __init__(self):
         self.index, self.total = 0, 1
         self.kept: dict = {}  # id(weight) -> (weight, [(dy2, x2), ...])
         self.kept_bytes = 0   # of the micro-batch `index`
         self.budget = None    # bytes one micro-batch may keep; measured at the window's first keep
+        self.transposed: dict = {}  # (id(weight), row padding) -> (weight, transposed copy) for the input-gradient GEMMs
 
     def clear(self):
         self.kept.clear()
+        self.transposed.clear()
         self.kept_bytes = 0
         self.budget = None
 

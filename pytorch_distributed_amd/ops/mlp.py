@@ -41,7 +41,11 @@ class _GeluMLPFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        u, g = ext.gemm_fused(x2, w_fc, b_fc, "bias_gelu", None)
+        if _mode() == "bwd":  # library GEMM + activation kernel forward, fused epilogue in backward only
+            u = planned_mm(x2, w_fc, trans_b=True, bias=b_fc)
+            g = ext.gelu_forward(u)
+        else:
+            u, g = ext.gemm_fused(x2, w_fc, b_fc, "bias_gelu", None)
         y = torch.empty(*x.shape[:-1], w_proj.shape[0], dtype=x.dtype, device=x.device)
         planned_mm(g, w_proj, trans_b=True, bias=b_proj, out=y.view(-1, w_proj.shape[0]))
         ctx.save_for_backward(x2, u, g, w_fc, w_proj)
@@ -69,8 +73,13 @@ class _GeluMLPFn(torch.autograd.Function):
         return dx, dw_fc, db_fc, dw_proj, db_proj
 
 
+def _mode() -> str:
+    """"0" (off), "1" (both epilogues) or "bwd" (only the gelu' multiply of the backward)."""
+    return os.environ.get("PDA_FUSED_MLP", "0")
+
+
 def _fused_ok(x, w_fc, b_fc, w_proj, b_proj) -> bool:
-    if os.environ.get("PDA_FUSED_MLP", "0") != "1" or not _ext.use_hip(x):
+    if _mode() not in ("1", "bwd") or not _ext.use_hip(x):
         return False
     if x.dtype != torch.bfloat16 or b_fc is None or b_proj is None:
         return False
