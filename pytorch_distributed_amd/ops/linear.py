@@ -240,15 +240,19 @@ def pending_weight_grads() -> int:
     return len(_WINDOW.kept)
 
 
+def _free_bytes(device) -> int:
+    """Device memory a new allocation can still get: free at the driver plus cached by the allocator."""
+    free, _ = torch.cuda.mem_get_info(device)
+    return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+
+
 def _keep_for_later(dy2, x2, weight) -> bool:
     """Keeps one (dY, X) pair for the window's last backward; False when the budget is used up."""
     w = _WINDOW
     if w.budget is None:
-        free, _ = torch.cuda.mem_get_info(dy2.device)
-        cached = torch.cuda.memory_reserved(dy2.device) - torch.cuda.memory_allocated(dy2.device)
         # Measured where a backward starts, i.e. at the activation peak: what is free now is what the
         # later micro-batches' kept operands can grow into.
-        w.budget = int(0.8 * (free + cached)) // max(1, w.total - 1)
+        w.budget = int(0.8 * _free_bytes(dy2.device)) // max(1, w.total - 1)
     size = dy2.numel() * dy2.element_size() + x2.numel() * x2.element_size()
     if w.kept_bytes + size > w.budget:
         return False

@@ -21,6 +21,7 @@ from typing import Any, Optional
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..parallel import comm
 from ..utils.profiler import annotate
 from .trainer import Trainer
@@ -74,7 +75,12 @@ class DistributedTrainer(Trainer):
         return loss.detach()
 
     def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:
-        return self.training_step(inputs, targets, should_sync=is_last_microbatch)
+        if not self.ddp_enabled:  # every micro-batch synchronises: gradients are read in between
+            return self.training_step(inputs, targets, should_sync=True)
+        # gradients are read only at the synchronising micro-batch: weight gradients once per window
+        accum = self.grad_accumulation_steps
+        with ops.accumulation_window(self.batch_count % accum, accum):
+            return self.training_step(inputs, targets, should_sync=is_last_microbatch)
 
     def _aggregate_loss(self, loss: float, device) -> float:
         """Mean of the ranks' window losses. Every rank calls this on logging steps."""

@@ -55,7 +55,7 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
     ap.add_argument("--metrics-file", default=None)
     ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="selective")
     ap.add_argument("--grad-accum-dtype", choices=["auto", "param", "fp32"], default="auto",
-                    help="distributed scripts: dtype in which the micro-batches of an accumulation window are "
+                    help="dtype in which the micro-batches of an accumulation window are "
                          "summed; auto = fp32 when bf16 gradients are accumulated over more than one micro-batch "
                          "(the reference accumulates in fp32), the parameter dtype otherwise")
     return ap

@@ -54,3 +54,29 @@ def test_smoke_entry():
     proc = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
     assert proc.returncode == 0, proc.stderr[-2000:]
+
+
+def test_bench_reports_the_reference_recipe_next_to_the_headline():
+    """Without --no-reference-recipe the same JSON line carries a second, short measurement of the
+    reference's recipe (32 sequences as 4 micro-batches of 8, selective recomputation)."""
+    res = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--model", "gpt2",
+                "--batch-per-gpu", "8", "--micro-batch", "8", "--reference-steps", "2"])
+    _check(res, 1, 2, 1, "single")
+    ref = res["reference_recipe"]
+    assert "error" not in ref, ref
+    assert ref["global_batch"] == 32 and ref["micro_batch"] == 8 and ref["grad_accum"] == 4
+    assert ref["activation_checkpoint"] == "selective" and ref["steps"] == 2
+    assert abs(ref["value"] - 32 * 1024 / (ref["ms_per_step"] / 1e3)) < 1e-6 * ref["value"]
+
+
+def test_train_baseline_script_accumulates_in_fp32_buffers_and_defers_weight_gradients():
+    """The single-GPU script at its own recipe shape (4 micro-batches per step) on a small model: the loss
+    falls, the fp32 accumulation wrapper is in place, nothing is left pending."""
+    proc = subprocess.run([sys.executable, "train_baseline.py", "--synthetic-data", "--model", "gpt2", "--max-steps", "6",
+                           "--log-every", "1", "--no-profile", "--global-batch-size", "16", "--micro-batch-size", "4",
+                           "--sequence-length", "256", "--dropout", "0"],
+                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert "Gradient accumulation in fp32 buffers" in proc.stdout
+    losses = [float(ln.split("loss=")[1].split()[0]) for ln in proc.stdout.splitlines() if "loss=" in ln]
+    assert len(losses) >= 5 and losses[-1] < losses[0], losses

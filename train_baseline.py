@@ -27,6 +27,12 @@ def main():
           f"Gradient accumulation steps: {args.global_batch_size // args.micro_batch_size}\n"
           f"Sequence length: {args.sequence_length}")
     loader = cli.build_loader(args, cfg, device, distributed=False)
+    if device == "cuda" and cli.resolve_grad_accum_dtype(args, dtype) == "fp32":
+        # bf16 gradients summed over several micro-batches: sum them in fp32 buffers, as the reference's
+        # fp32 training loop does (assignments/assignment1/train/trainer.py:57-61)
+        from pytorch_distributed_amd.parallel import GradAccumulator
+        model = GradAccumulator(model, grad_accum_dtype="fp32")
+        print("Gradient accumulation in fp32 buffers")
     optimizer, scheduler = cli.build_optimizer(args, model.parameters())
     trainer = Trainer(model, optimizer, scheduler, max_steps=args.max_steps,
                       global_batch_size=args.global_batch_size, micro_batch_size=args.micro_batch_size,
