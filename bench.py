@@ -85,10 +85,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-reference-recipe", action="store_true",
                     help="skip the second, short measurement at the reference's recipe (32 = 4 x 8, selective)")
     ap.add_argument("--reference-steps", type=int, default=5, help="timed steps of the reference-recipe measurement")
-    ap.add_argument("--comm-dual", choices=["auto", "on", "off"], default="auto",
+    ap.add_argument("--comm-dual", choices=["auto", "on", "off"], default="off",
                     help="second RCCL communicator for the all-gather queue: auto = created on multi-GPU jobs and "
                          "used only when the start-up measurement finds an all-gather behind a reduce-scatter faster "
-                         "that way")
+                         "that way. Off by default: two library communicators working at once have only ever run "
+                         "at world size 1 here, and the default run must not depend on them")
     ap.add_argument("--planner-stats", action="store_true", help="print the GEMM planner's per-shape choices to stderr")
     ap.add_argument("--hip-graph", action="store_true",
                     help="single GPU, experimental: record the whole optimizer step into a HIP graph and replay it")
@@ -168,6 +169,15 @@ def run_modes(kinds, measure, communicator_state):
             if communicator_state() in ("none", "aborted"):
                 break
     return results, [k for k in kinds if k in results and "error" not in results[k]]
+
+
+def should_relaunch_on_fallback(comm_flag: str, world: int, communicator, environ) -> bool:
+    """After a run in which NO mode could be measured: try once more on the torch.distributed backend?
+    Only for ``--comm auto``, only when the failed run was on the native communicator of a multi-rank
+    job, and never from a process that already is such a second try."""
+    if comm_flag != "auto" or world <= 1 or environ.get("PDA_COMM_RELAUNCHED") == "1":
+        return False
+    return communicator is None or getattr(communicator, "backend", "") in ("rccl", "socket")
 
 
 def main():
@@ -347,7 +357,25 @@ def main():
         return "none" if c is None else ("aborted" if getattr(c, "aborted", False) else "ok")
 
     kinds = {"single": ["single"], "ddp": ["ddp"], "fsdp": ["fsdp"], "both": ["ddp", "fsdp"]}[mode]
-    results, good = run_modes(kinds, measure, communicator_state)
+    try:
+        results, good = run_modes(kinds, measure, communicator_state)
+    except Exception as exc:  # noqa: BLE001 - a single mode propagates; a second try below may still apply
+        if not should_relaunch_on_fallback(args.comm, world, comm.get_communicator(), os.environ):
+            raise
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        results, good = {kinds[0]: {"parallelism": kinds[0], "error": repr(exc)[:500]}}, []
+    if not good and should_relaunch_on_fallback(args.comm, world, comm.get_communicator(), os.environ):
+        # The native communicator passed its start-up test and then failed or timed out in a measured step (every
+        # rank's watchdog aborts, so every rank arrives here): a measurement on the torch.distributed backend is
+        # worth more than none. A fresh child process per rank, because an aborted library communicator cannot
+        # be revived in this one; this process only waits for it.
+        print(f"[bench] rank {rank}: no mode could be measured on the native communicator ({results}); "
+              "running again on the torch.distributed backend", file=sys.stderr, flush=True)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        comm.relaunch_self_on_c10d()
     if not good:
         raise SystemExit(f"no mode could be measured: {results}")
     head = results[good[-1]]  # FSDP when both were measured

@@ -85,6 +85,23 @@ def test_bench_records_an_aborted_mode_and_stops():
         bench.run_modes(["ddp"], flaky, lambda: "ok")
 
 
+def test_bench_second_try_on_the_fallback_backend_only_when_it_can_help():
+    """No mode measured on the native communicator of a multi-rank `--comm auto` job: each rank runs the
+    benchmark again as a child on torch.distributed — once, never from such a child, never for one rank."""
+    bench = _load_bench()
+
+    class C:
+        def __init__(self, backend):
+            self.backend = backend
+
+    assert bench.should_relaunch_on_fallback("auto", 8, C("rccl"), {})
+    assert bench.should_relaunch_on_fallback("auto", 2, None, {})                 # communicator already shut down
+    assert not bench.should_relaunch_on_fallback("auto", 8, C("c10d"), {})        # already on the fallback
+    assert not bench.should_relaunch_on_fallback("native", 8, C("rccl"), {})      # the caller pinned the backend
+    assert not bench.should_relaunch_on_fallback("auto", 1, C("rccl"), {})
+    assert not bench.should_relaunch_on_fallback("auto", 8, C("rccl"), {"PDA_COMM_RELAUNCHED": "1"})
+
+
 def test_bench_launch_plan_flips_backend_then_ipc_mode(monkeypatch):
     """The parent's retries: native, then torch.distributed, then torch.distributed with the IPC
     variable as the caller had it; every attempt is recorded in the result line."""
