@@ -24,12 +24,13 @@ def pg():
     shutdown()
 
 
-def _model(seed=0, n_layer=3):
+def _model(seed=0, n_layer=3, activation_checkpoint=None):
     from pytorch_distributed_amd.models import MyGPT2LMHeadModel, get_config
 
     torch.manual_seed(seed)
     cfg = get_config("gpt2", n_layer=n_layer).without_dropout()
-    return MyGPT2LMHeadModel(cfg).to(device=DEV, dtype=torch.bfloat16), cfg
+    kw = {} if activation_checkpoint is None else {"activation_checkpoint": activation_checkpoint}
+    return MyGPT2LMHeadModel(cfg, **kw).to(device=DEV, dtype=torch.bfloat16), cfg
 
 
 def _train(model, params, ids, steps=4, accum=2, no_sync=None):
@@ -263,8 +264,8 @@ def test_in_process_kernel_trace(tmp_path):
     assert first >= ta.step_window(ev, 2)[0] - 2000, (first, ta.step_window(ev, 2))
 
 
-@pytest.mark.parametrize("wrapper,accum", [("plain", 4), ("plain", 3), ("plain", 6), ("ddp", 4), ("ddp_fp32", 4),
-                                           ("fsdp", 4), ("fsdp_grad_op", 2)])
+@pytest.mark.parametrize("wrapper,accum", [("plain", 4), ("plain", 3), ("plain", 6), ("plain_full", 4), ("plain_none", 2),
+                                           ("ddp", 4), ("ddp_fp32", 4), ("fsdp", 4), ("fsdp_grad_op", 2), ("fsdp_full", 2)])
 def test_weight_gradients_deferred_over_the_accumulation_window(pg, wrapper, accum, monkeypatch):
     """Inside ops.linear.accumulation_window the (dY, X) pairs of the earlier micro-batches are kept and
     the last backward forms each weight gradient as one product over the whole window: same training
@@ -274,7 +275,8 @@ def test_weight_gradients_deferred_over_the_accumulation_window(pg, wrapper, acc
     from pytorch_distributed_amd.parallel import DDP, ShardingStrategy, fsdp_wrap_gpt
 
     def build():
-        model, cfg = _model(7)
+        policy = "full" if wrapper.endswith("_full") else "none" if wrapper.endswith("_none") else None
+        model, cfg = _model(7, activation_checkpoint=policy)  # full: the linear backward runs inside a block's recomputation
         if wrapper.startswith("ddp"):
             model = DDP(model, device_ids=[0], bucket_cap_mb=8, first_bucket_mb=1, force_collectives=True,
                         grad_accum_dtype="fp32" if wrapper == "ddp_fp32" else "param")
