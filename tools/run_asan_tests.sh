@@ -12,6 +12,8 @@ for f in pytorch_distributed_amd/*; do
 done
 ln -s "$(pwd)/build/asan/_C.so" "$OVERLAY/_C.so"
 ln -sfn "$(pwd)/tests" build/asan-overlay/tests
+# tests that load the entry scripts by path (bench.py, counter_profile.py, ...) look next to tests/
+for f in *.py tools; do ln -sfn "$(pwd)/$f" "build/asan-overlay/$f"; done
 # the sanitizer runtimes go first; whatever the environment already preloads is kept
 export LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)${LD_PRELOAD:+:$LD_PRELOAD}"
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0
