@@ -213,8 +213,8 @@ def main():
     from pytorch_distributed_amd.parallel import autotune, comm
     from pytorch_distributed_amd.utils.flops import model_flops_per_token
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = comm.local_device(local_rank)  # LOCAL_RANK, or a shared GPU in a rehearsal (PDA_SHARED_GPU=1)
+    torch.cuda.set_device(device)
     comm.RELAUNCH_STDOUT_FD = real_stdout  # a rank relaunched on the fallback backend prints the line there
     mode = args.mode
     if mode == "auto":
@@ -279,7 +279,7 @@ def main():
         if kind == "ddp":
             from pytorch_distributed_amd.parallel import DDP
             decompose = {"auto": None, "on": True, "off": False}[args.ddp_decompose]
-            model = DDP(model, device_ids=[local_rank], force_collectives=args.wrap_single,
+            model = DDP(model, device_ids=[device.index], force_collectives=args.wrap_single,
                         reduce_fp32=args.reduce_fp32, bucket_cap_mb=args.bucket_mb, decompose=decompose)
             parallelism = f"ddp{world}"
             detail = {"bucket_mb": model.bucket_cap_mb, "decompose": model.decompose,

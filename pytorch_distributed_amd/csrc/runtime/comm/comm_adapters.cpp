@@ -50,17 +50,27 @@ class C10dWork final : public Work {
 
 class C10dCommunicator final : public Communicator {
  public:
-  explicit C10dCommunicator(c10::intrusive_ptr<c10d::ProcessGroup> pg) : pg_(std::move(pg)) {
+  // `device_tensors`: the group is given GPU tensors although its backend is a host one (gloo stages
+  // them through host memory): several ranks rehearsing on one GPU, which the GPU library refuses.
+  explicit C10dCommunicator(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool device_tensors = false)
+      : pg_(std::move(pg)), device_tensors_(device_tensors) {
     TORCH_CHECK(pg_, "C10dCommunicator: null process group");
     name_ = pg_->getBackendName();
   }
   int rank() const override { return pg_->getRank(); }
   int world() const override { return pg_->getSize(); }
   std::string backend() const override { return "c10d:" + name_; }
-  bool on_gpu() const override { return name_ == "nccl"; }
+  bool on_gpu() const override { return name_ == "nccl" || device_tensors_; }
 
   std::shared_ptr<Work> all_reduce(const at::Tensor& t, RedOp op, Queue) override {
     check_collective_args("all_reduce", t, t, 1, t.is_cuda());
+    if (staged(t)) {  // rehearsal on a shared GPU: through host memory, complete on return (counted by the inner call)
+      at::NoGradGuard ng;
+      at::Tensor host = t.cpu();
+      all_reduce(host, op, Queue::kReduce)->wait();
+      at::Tensor(t).copy_(host);
+      return std::make_shared<CompletedWork>();
+    }
     count(Kind::kAllReduce, t);
     std::vector<at::Tensor> ts{t};
     c10d::AllreduceOptions opts;
@@ -80,12 +90,26 @@ class C10dCommunicator final : public Communicator {
   std::shared_ptr<Work> all_gather(const at::Tensor& out, const at::Tensor& in, Queue) override {
     check_collective_args("all_gather", out, in, world(), out.is_cuda());
     count(Kind::kAllGather, out);
+    if (staged(out)) {
+      at::NoGradGuard ng;
+      at::Tensor host_in = in.cpu(), host_out = at::empty(out.sizes(), host_in.options());
+      pg_->_allgather_base(host_out, host_in)->wait();
+      at::Tensor(out).copy_(host_out);
+      return std::make_shared<CompletedWork>();
+    }
     at::Tensor o = out, i = in;
     return std::make_shared<C10dWork>(pg_->_allgather_base(o, i), std::vector<at::Tensor>{out, in});
   }
 
   std::shared_ptr<Work> reduce_scatter(const at::Tensor& out, const at::Tensor& in, RedOp op, Queue) override {
     check_collective_args("reduce_scatter", in, out, world(), out.is_cuda());
+    if (staged(in)) {
+      at::NoGradGuard ng;
+      at::Tensor host_in = in.cpu(), host_out = at::empty(out.sizes(), host_in.options());
+      reduce_scatter(host_out, host_in, op, Queue::kReduce)->wait();
+      at::Tensor(out).copy_(host_out);
+      return std::make_shared<CompletedWork>();
+    }
     count(Kind::kReduceScatter, in);
     at::Tensor o = out, i = in;
     c10d::ReduceScatterOptions opts;
@@ -103,6 +127,13 @@ class C10dCommunicator final : public Communicator {
   }
 
   std::shared_ptr<Work> broadcast(const at::Tensor& t, int root, Queue) override {
+    if (staged(t)) {
+      at::NoGradGuard ng;
+      at::Tensor host = t.cpu();
+      broadcast(host, root, Queue::kGather)->wait();
+      at::Tensor(t).copy_(host);
+      return std::make_shared<CompletedWork>();
+    }
     count(Kind::kBroadcast, t);
     std::vector<at::Tensor> ts{t};
     c10d::BroadcastOptions opts;
@@ -116,7 +147,7 @@ class C10dCommunicator final : public Communicator {
   std::vector<std::string> exchange(const std::string& mine) override {
     if (world() <= 1) return {mine};
     // Two rounds over the group: lengths, then padded payloads.
-    const auto dev = on_gpu() ? at::Device(at::kCUDA) : at::Device(at::kCPU);
+    const auto dev = name_ == "nccl" ? at::Device(at::kCUDA) : at::Device(at::kCPU);
     auto gather = [&](const at::Tensor& local) {
       std::vector<at::Tensor> outs;
       for (int r = 0; r < world(); ++r) outs.push_back(at::empty_like(local));
@@ -141,8 +172,14 @@ class C10dCommunicator final : public Communicator {
   }
 
  private:
+  // GPU tensor on a host backend: staged through host memory here, synchronously, instead of through
+  // the backend's own device path (with several processes on one GPU its copy streams and pinned
+  // buffers were seen to leave two ranks waiting for each other).
+  bool staged(const at::Tensor& t) const { return device_tensors_ && t.is_cuda() && name_ != "nccl"; }
+
   c10::intrusive_ptr<c10d::ProcessGroup> pg_;
   std::string name_;
+  bool device_tensors_ = false;
 };
 
 }  // namespace
@@ -300,8 +337,8 @@ std::shared_ptr<Communicator> make_hanging_communicator(std::shared_ptr<Communic
   return std::make_shared<HangingCommunicator>(std::move(inner), healthy_calls, timeout_s);
 }
 
-std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg) {
-  return std::make_shared<C10dCommunicator>(std::move(pg));
+std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool device_tensors) {
+  return std::make_shared<C10dCommunicator>(std::move(pg), device_tensors);
 }
 
 std::shared_ptr<Communicator> make_recording_communicator(std::shared_ptr<Communicator> inner) {

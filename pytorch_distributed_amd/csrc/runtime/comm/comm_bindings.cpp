@@ -19,7 +19,7 @@ std::pair<bool, bool> rccl_dual_route(const std::shared_ptr<Communicator>& c, in
 std::shared_ptr<Communicator> make_hanging_communicator(std::shared_ptr<Communicator> inner, int64_t healthy_calls,
                                                         double timeout_s);
 std::shared_ptr<Communicator> make_socket_communicator(std::shared_ptr<Rendezvous> rv, double timeout_s);
-std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg);
+std::shared_ptr<Communicator> make_c10d_communicator(c10::intrusive_ptr<c10d::ProcessGroup> pg, bool device_tensors);
 std::shared_ptr<Communicator> make_recording_communicator(std::shared_ptr<Communicator> inner);
 std::vector<std::tuple<std::string, int64_t, int>> recording_log(const std::shared_ptr<Communicator>& c, bool clear);
 int64_t rccl_stream_handle(const std::shared_ptr<Communicator>& c, int q);
@@ -206,7 +206,7 @@ void bind_comm(py::module_& m) {
         return keys;
       },
       py::arg("world"), py::arg("rounds"), py::arg("port"), py::call_guard<py::gil_scoped_release>());
-  m.def("wrap_process_group", &make_c10d_communicator, py::arg("process_group"));
+  m.def("wrap_process_group", &make_c10d_communicator, py::arg("process_group"), py::arg("device_tensors") = false);
   m.def("recording_communicator", &make_recording_communicator, py::arg("inner"));
   m.def("hanging_communicator", &make_hanging_communicator, py::arg("inner"), py::arg("healthy_calls"),
         py::arg("timeout_s"),

@@ -77,6 +77,20 @@ def relaunch_self_on_c10d() -> "NoReturn":  # noqa: F821
     os._exit(code)  # not sys.exit: the stuck helper thread must not be joined by interpreter shutdown
 
 
+def shared_gpu_rehearsal() -> bool:
+    """``PDA_SHARED_GPU=1``: several ranks of one job share a GPU (rank r uses GPU ``LOCAL_RANK`` modulo
+    the number of visible ones). The collective library refuses two ranks on one device, so such a job
+    runs over torch.distributed's gloo backend (device tensors staged through the host): slow, and
+    meant for one thing only — rehearsing the multi-rank DDP / FSDP runtimes WITH the GPU kernels on a
+    machine that has fewer GPUs than ranks."""
+    return os.environ.get("PDA_SHARED_GPU") == "1"
+
+
+def local_device(local_rank: int) -> torch.device:
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % n if shared_gpu_rehearsal() and n > 0 else local_rank)
+
+
 def env_rank_world() -> Tuple[int, int, int]:
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
             int(os.environ.get("LOCAL_RANK", 0)))
@@ -203,6 +217,8 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
         backend = os.environ.get("PDA_COMM_BACKEND") or ("rccl" if torch.cuda.is_available() else "socket")
     if dual is None:
         dual = os.environ.get("PDA_COMM_DUAL", "0") == "1"
+    if shared_gpu_rehearsal() and backend == "rccl" and world > 1:
+        backend = "c10d"  # gloo below: the collective library does not take two ranks on one device
     if fallback not in (None, "c10d"):
         raise ValueError("fallback must be None or 'c10d'")
     ext = _ext.require()
@@ -211,7 +227,7 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
     if backend == "rccl":
         if not torch.cuda.is_available():
             raise RuntimeError("the 'rccl' communicator needs a GPU; use backend='socket' on CPUs")
-        device = torch.device("cuda", local_rank)
+        device = local_device(local_rank)
         torch.cuda.set_device(device)
         torch.zeros(1, device=device)  # the HIP context exists before RCCL initialises
         create = lambda: ext.create_communicator("rccl", rank, world, host, _store_port(), local_rank,  # noqa: E731
@@ -245,19 +261,20 @@ def init_distributed(backend: Optional[str] = None, timeout_s: float = 600.0, fa
         import torch.distributed as dist
 
         use_gpu = torch.cuda.is_available()
-        device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+        device = local_device(local_rank) if use_gpu else torch.device("cpu")
         if use_gpu:
             torch.cuda.set_device(device)
+        library = use_gpu and not (shared_gpu_rehearsal() and world > 1)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            kwargs = dict(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world,
+            kwargs = dict(backend="nccl" if library else "gloo", rank=rank, world_size=world,
                           timeout=datetime.timedelta(seconds=timeout_s))
-            if use_gpu:
+            if library:
                 kwargs["device_id"] = device
             dist.init_process_group(**kwargs)
             _OWNS_C10D = True
-        _COMM = ext.wrap_process_group(dist.distributed_c10d._get_default_group())
+        _COMM = ext.wrap_process_group(dist.distributed_c10d._get_default_group(), use_gpu and not library)
     else:
         raise ValueError(f"unknown communicator backend {backend!r} (rccl, socket, c10d)")
     _DEVICE = device

@@ -24,6 +24,9 @@ def _entry(rank, world, port, fn, args, err_dir, backend="socket"):
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     torch.set_num_threads(2)
+    if os.environ.get("PDA_TEST_DUMP_AFTER"):  # diagnosis of a stuck rank: Python stacks of all threads to stderr
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PDA_TEST_DUMP_AFTER"]), exit=False)
     try:
         from pytorch_distributed_amd.parallel import init_distributed, shutdown
 
