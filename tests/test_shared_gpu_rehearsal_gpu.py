@@ -39,10 +39,14 @@ def _train(rank, world, kind, accum):
     assert get_communicator().backend == "c10d:gloo" and get_communicator().world_size == world
     ref, cfg = _model(11)
     model = copy.deepcopy(ref)
-    if kind == "ddp":
-        wrapped = DDP(model, bucket_cap_mb=8, first_bucket_mb=1)
-    elif kind == "ddp_fp32":
-        wrapped = DDP(model, bucket_cap_mb=8, first_bucket_mb=1, grad_accum_dtype="fp32")
+    if kind.startswith("ddp"):
+        wrapped = DDP(model, bucket_cap_mb=8, first_bucket_mb=1, decompose=kind == "ddp_decompose",
+                      reduce_fp32=kind == "ddp_reduce_fp32", grad_accum_dtype="fp32" if kind == "ddp_fp32" else None)
+    elif kind == "FULL_SHARD_resident":  # the last units keep their gathered parameters from forward to backward
+        wrapped = fsdp_wrap_gpt(model, ShardingStrategy.FULL_SHARD, resident_gb="auto")
+    elif kind == "FULL_SHARD_units2":    # two blocks per flat-parameter unit, fp32 reduce-scatter and accumulation
+        wrapped = fsdp_wrap_gpt(model, ShardingStrategy.FULL_SHARD, unit_blocks=2, reduce_fp32=True,
+                                grad_accum_dtype="fp32")
     else:
         wrapped = fsdp_wrap_gpt(model, ShardingStrategy[kind])
     opt_ref = FusedAdamW(ref.parameters(), lr=1e-3, weight_decay=0.1)
@@ -81,8 +85,10 @@ def _train(rank, world, kind, accum):
         assert (sd[k].float().cpu() - ref_sd[k].float().cpu()).abs().max().item() < 1.5e-2, k
 
 
-@pytest.mark.parametrize("kind,world,accum", [("ddp", 2, 1), ("ddp", 2, 2), ("ddp_fp32", 2, 2), ("FULL_SHARD", 2, 1),
-                                              ("FULL_SHARD", 3, 2), ("SHARD_GRAD_OP", 2, 2), ("FULL_SHARD", 4, 1)])
+@pytest.mark.parametrize("kind,world,accum", [("ddp", 2, 1), ("ddp", 2, 2), ("ddp_fp32", 2, 2), ("ddp_decompose", 3, 2),
+                                              ("ddp_reduce_fp32", 2, 1), ("FULL_SHARD", 2, 1), ("FULL_SHARD", 3, 2),
+                                              ("SHARD_GRAD_OP", 2, 2), ("NO_SHARD", 2, 2), ("FULL_SHARD", 4, 1),
+                                              ("FULL_SHARD_resident", 2, 2), ("FULL_SHARD_units2", 2, 2)])
 def test_multi_rank_training_on_one_shared_gpu_matches_single_process(kind, world, accum, monkeypatch):
     monkeypatch.setenv("PDA_SHARED_GPU", "1")
     run_distributed(_train, world=world, args=(kind, accum), timeout=200.0, backend="rccl")
