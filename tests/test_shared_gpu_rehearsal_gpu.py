@@ -140,7 +140,10 @@ def test_bench_and_train_scripts_with_two_ranks_on_one_shared_gpu(tmp_path):
 
     from tests.dist_utils import ROOT, free_port
 
-    env = dict(os.environ, PDA_SHARED_GPU="1", OMP_NUM_THREADS="4")
+    # (a launcher's variables left in this process by another test module must not reach the children)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PDA_COMM_BACKEND")}
+    env.update(PDA_SHARED_GPU="1", OMP_NUM_THREADS="4")
     proc = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--model", "gpt2", "--batch-per-gpu", "4",
                            "--micro-batch", "4", "--steps", "2", "--warmup", "1", "--reference-steps", "1"],
                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
