@@ -242,3 +242,32 @@ def test_fused_mlp_path_matches_the_separate_ops(monkeypatch):
 
     for a, b in zip(run("1"), run("0")):
         assert rel_err(a, b) < 1e-2
+
+
+@pytest.mark.parametrize("policy", ["none", "selective", "full"])
+def test_llama_gradients_over_an_accumulation_window_match_per_micro_batch_products(monkeypatch, policy):
+    """Llama blocks (bias-free projections, SwiGLU, RMSNorm) with the weight gradients of four micro-batches
+    formed once: same gradients as a product per micro-batch, for every activation policy."""
+    from pytorch_distributed_amd import ops
+    from pytorch_distributed_amd.models import LlamaForCausalLM
+
+    cfg = get_config("llama-tiny", n_embd=512, n_head=4, intermediate_size=1024, n_ctx=256).without_dropout()
+    ids = [torch.randint(0, cfg.vocab_size, (4, 257), device=DEV, generator=torch.Generator(device=DEV).manual_seed(i))
+           for i in range(4)]
+
+    def grads(defer):
+        monkeypatch.setenv("PDA_DEFER_WGRAD", "1" if defer else "0")
+        torch.manual_seed(0)
+        model = LlamaForCausalLM(cfg, activation_checkpoint=policy).to(device=DEV, dtype=torch.bfloat16)
+        for i, x in enumerate(ids):
+            with ops.accumulation_window(i, 4):
+                (model(x[:, :-1], x[:, 1:]) / 4).backward()
+            if defer and i < 3:
+                assert ops.pending_weight_grads() == 2 * 4  # q/k/v (packed), o, gate/up (packed), down per block
+        assert ops.pending_weight_grads() == 0
+        return {n: p.grad.float() for n, p in model.named_parameters()}
+
+    d, p = grads(True), grads(False)
+    assert d.keys() == p.keys()
+    for n in p:
+        assert rel_err(d[n], p[n]) < 2e-2, n
