@@ -292,6 +292,7 @@ class ShardedUnit {
   int64_t num_allgathers() const { return num_allgathers_; }
   int64_t num_reductions() const { return num_reductions_; }
   bool reshard_after_forward = true;  // FULL_SHARD non-root units; the wrapper clears it for the root
+  bool window_resident_ = false;      // set with the runtime's resident budget
 
   // Gradient sink: hands an op the slice of the flat gradient buffer that belongs to parameter
   // `i`, so the op's weight-gradient kernel writes (or, second element true, accumulates) there
@@ -541,6 +542,7 @@ class ShardedRuntime {
     std::lock_guard<std::recursive_mutex> lock(mu_);
     resident_.assign(units_.size(), false);
     resident_bytes_ = 0;
+    for (auto& u : units_) u->window_resident_ = false;
     int64_t count = 0;
     for (int64_t i = (int64_t)units_.size() - 1; i >= 1; --i) {
       ShardedUnit& u = *units_[i];
@@ -548,6 +550,7 @@ class ShardedRuntime {
       const int64_t unit_bytes = u.padded_numel_ * (int64_t)u.full_param_.element_size();
       if (resident_bytes_ + unit_bytes > bytes) break;
       resident_[i] = true;
+      u.window_resident_ = true;
       resident_bytes_ += unit_bytes;
       ++count;
     }
@@ -665,7 +668,11 @@ void ShardedUnit::on_grad_ready(size_t i) {
     // FULL_SHARD: every kernel of this unit's backward is already enqueued; release the
     // unsharded parameters now rather than at the end of backward (also under no_sync,
     // where only the gradients stay unsharded).
-    if (strategy_ == kFullShard && reshard_after_forward) reshard();
+    // A unit inside the resident budget stays gathered through a no_sync window as well: no optimizer
+    // step can change its parameters before the window's last backward, so the next micro-batch's
+    // forward finds them in place instead of gathering them again.
+    const bool stays = window_resident_ && !runtime_->sync_enabled();
+    if (strategy_ == kFullShard && reshard_after_forward && !stays) reshard();
   }
 }
 

@@ -109,6 +109,46 @@ def test_fsdp_resident_budget_two_ranks():
     run_distributed(_fsdp_resident_budget, world=2)
 
 
+def _fsdp_resident_window(rank, world):
+    """Resident units stay gathered across the micro-batches of a no_sync window (their parameters cannot
+    change before the window's last backward): one all-gather per unit and step instead of one per
+    micro-batch and pass; same training; everything resharded once the synchronising backward is done."""
+    from pytorch_distributed_amd.optim import FusedAdamW
+    from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
+
+    base = _tiny_model(8)
+    plain = fsdp_wrap_gpt(copy.deepcopy(base), ShardingStrategy.FULL_SHARD)
+    kept = fsdp_wrap_gpt(copy.deepcopy(base), ShardingStrategy.FULL_SHARD, resident_gb=1.0)
+    opts = [FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.1) for m in (plain, kept)]
+    units = lambda m: [u.unit for u in m.modules() if type(u).__name__ == "FSDP"]  # noqa: E731
+    gathers = lambda m: sum(u.num_allgathers for u in units(m))  # noqa: E731
+    n_blocks, accum = len(base.transformer.h), 3
+    for step in range(2):
+        x, y = _batch(900 + step, 2 * world * accum)
+        before = [gathers(plain), gathers(kept)]
+        for m, o in zip((plain, kept), opts):
+            for a in range(accum):
+                lo = (a * world + rank) * 2
+                if a < accum - 1:
+                    with m.no_sync():
+                        (m(x[lo:lo + 2], y[lo:lo + 2]) / accum).backward()
+                    if m is kept:  # blocks (resident) and root are still gathered between micro-batches
+                        assert all(u.is_unsharded() for u in units(m))
+                else:
+                    (m(x[lo:lo + 2], y[lo:lo + 2]) / accum).backward()
+            assert all(not u.is_unsharded() for u in units(m))
+            o.step(zero_grad=True)
+        # plain: every block twice per micro-batch, the root once per window (it never reshards inside one)
+        assert gathers(plain) - before[0] == 1 + 2 * n_blocks * accum
+        assert gathers(kept) - before[1] == 1 + n_blocks
+    for a, b in zip(plain.parameters(), kept.parameters()):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_fsdp_resident_units_stay_gathered_through_a_no_sync_window():
+    run_distributed(_fsdp_resident_window, world=2)
+
+
 def _fsdp_state_dict_roundtrip(rank, world):
     ref = _tiny_model(4)
     model = _wrap(copy.deepcopy(ref), "FULL_SHARD")
