@@ -132,9 +132,10 @@ def _delta(before):
 # FULL_SHARD, per step: the root is gathered once (it stays gathered until the synchronising backward
 # ends), every block unit in each forward and again in each backward: 1 + 4 U all-gathers; one
 # reduce-scatter per unit.
-# With every block resident the backward all-gathers disappear: 1 + 2 U.
+# With every block resident the backward all-gathers disappear and the units stay gathered through the
+# no_sync micro-batch: one all-gather per unit and step, 1 + U.
 @pytest.mark.parametrize("n_layer,unit_blocks,resident,all_gathers_per_step", [
-    (3, 1, 0.0, 1 + 4 * 3), (6, 3, 0.0, 1 + 4 * 2), (3, 1, "auto", 1 + 2 * 3)])
+    (3, 1, 0.0, 1 + 4 * 3), (6, 3, 0.0, 1 + 4 * 2), (3, 1, "auto", 1 + 3)])
 def test_fsdp_full_shard_exact_collective_counts(pg, n_layer, unit_blocks, resident, all_gathers_per_step):
     from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
 
