@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--fsdp-resident-gb", default="0",
                     help="FULL_SHARD: GiB of unsharded parameters kept from forward to backward ('auto' = a tenth of "
                          "free memory); 0 = every unit is all-gathered again in backward")
+    ap.add_argument("--no-resident-variant", action="store_true",
+                    help="--mode both: do not measure the third row (FULL_SHARD with the resident budget 'auto')")
     ap.add_argument("--no-comm-autotune", action="store_true", help="skip the start-up collective measurement")
     ap.add_argument("--comm", choices=["auto", "native", "c10d"], default="auto",
                     help="native = the framework's RCCL communicator; c10d = a torch.distributed group behind the same "
@@ -284,7 +286,7 @@ def main():
             parallelism = f"ddp{world}"
             detail = {"bucket_mb": model.bucket_cap_mb, "decompose": model.decompose,
                       "buckets": model.reducer.num_buckets}
-        elif kind == "fsdp":
+        elif kind in ("fsdp", "fsdp_resident"):
             from pytorch_distributed_amd.parallel import ShardingStrategy, fsdp_wrap_gpt
             unit_blocks = args.fsdp_unit_blocks
             if unit_blocks is None:
@@ -292,10 +294,12 @@ def main():
                 block_bytes = sum(p.numel() * p.element_size() for p in blocks[0].parameters())
                 unit_blocks = policy.fsdp_unit_blocks(block_bytes, len(blocks)) if policy is not None else 1
             resident = "auto" if args.fsdp_resident_gb == "auto" else float(args.fsdp_resident_gb)
+            if kind == "fsdp_resident":  # the same wrapper with the resident budget sized from free memory
+                resident = "auto"
             model = fsdp_wrap_gpt(model, ShardingStrategy[args.strategy], unit_blocks=unit_blocks,
                                   force_collectives=args.wrap_single, reduce_fp32=args.reduce_fp32,
                                   resident_gb=resident)
-            parallelism = f"fsdp_{args.strategy.lower()}{world}"
+            parallelism = f"fsdp_{args.strategy.lower()}{world}" + ("_resident" if kind == "fsdp_resident" else "")
             detail = {"unit_blocks": unit_blocks, "resident_gb": resident}
         else:
             parallelism = "single"
@@ -339,6 +343,8 @@ def main():
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             comm.all_reduce(t, "max")
             elapsed = float(t.item())
+        if kind in ("fsdp", "fsdp_resident"):
+            detail["resident_units"] = int(model.resident_units)  # chosen at the first forward
         tokens_per_step = batch_per_gpu * world * args.seq_len
         tps = tokens_per_step * steps / elapsed
         out = {"parallelism": parallelism, "value": tps, "ms_per_step": 1e3 * elapsed / steps,
@@ -357,6 +363,12 @@ def main():
         return "none" if c is None else ("aborted" if getattr(c, "aborted", False) else "ok")
 
     kinds = {"single": ["single"], "ddp": ["ddp"], "fsdp": ["fsdp"], "both": ["ddp", "fsdp"]}[mode]
+    if (mode == "both" and args.strategy == "FULL_SHARD" and args.fsdp_resident_gb in ("0", "0.0")
+            and not args.no_resident_variant):
+        # Third row: FULL_SHARD whose units keep their gathered parameters from forward to backward and through an
+        # accumulation window while they fit a tenth of free memory (288 GB per GPU: they do) — half the
+        # all-gather traffic of the strict form per step. The headline stays the strict form.
+        kinds = kinds + ["fsdp_resident"]
     try:
         results, good = run_modes(kinds, measure, communicator_state)
     except Exception as exc:  # noqa: BLE001 - a single mode propagates; a second try below may still apply
@@ -378,13 +390,14 @@ def main():
         comm.relaunch_self_on_c10d()
     if not good:
         raise SystemExit(f"no mode could be measured: {results}")
-    head = results[good[-1]]  # FSDP when both were measured
+    head_kind = "fsdp" if "fsdp" in good else ("ddp" if "ddp" in good else good[-1])  # strict FSDP when measured
+    head = results[head_kind]
 
     # The reference's own recipe, like for like, in the same process and wrapper as the headline.
     reference = None
     if not args.no_reference_recipe and not args.hip_graph and communicator_state() != "aborted":
         try:
-            reference = measure(good[-1], batch_per_gpu=32, micro_batch=8, activation_checkpoint="selective",
+            reference = measure(head_kind, batch_per_gpu=32, micro_batch=8, activation_checkpoint="selective",
                                 steps=args.reference_steps, warmup=2)
             reference.update({"global_batch": 32 * world, "micro_batch": 8, "grad_accum": 4, "seq_len": args.seq_len,
                               "activation_checkpoint": "selective", "steps": args.reference_steps, "warmup": 2,

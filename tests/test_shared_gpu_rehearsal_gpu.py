@@ -153,7 +153,10 @@ def test_bench_and_train_scripts_with_two_ranks_on_one_shared_gpu(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8
     assert res["config"]["comm_backend"] == "c10d:gloo"
-    assert set(res["modes"]) == {"ddp", "fsdp"} and all("error" not in m for m in res["modes"].values()), res["modes"]
+    assert set(res["modes"]) == {"ddp", "fsdp", "fsdp_resident"}, res["modes"]
+    assert all("error" not in m for m in res["modes"].values()), res["modes"]
+    assert res["config"]["parallelism"] == "fsdp_full_shard2"        # the headline is the strict form
+    assert res["modes"]["fsdp"]["resident_units"] == 0 and res["modes"]["fsdp_resident"]["resident_units"] > 0
     assert res["config"]["comm_policy"]["ddp_bucket_mb"] > 0          # the start-up measurement ran at world size 2
     assert "error" not in res["reference_recipe"] and res["reference_recipe"]["global_batch"] == 64
     assert res["launch_attempts"][0]["result"] is True
