@@ -27,14 +27,22 @@
 // result is deterministic. The price is recomputing S and dP in both kernels (7 matrix
 // products instead of 5); the alternative single-kernel form needs fp32 atomics for dQ.
 //
-// What bounds them: on gfx950 the matrix pipe and the vector ALU of a SIMD do not work at the
-// same time to any useful degree (tools/micro/coexec_probe.hip, mfma_probe.hip: beside a wave
-// issuing MFMAs back to back a second wave gets about one vector instruction per MFMA, and
-// inside one wave eight v_fma_f32 behind an MFMA cost 37 extra ticks). A SIMD therefore spends the
-// SUM of the tile's matrix work (24 MFMAs of 32 ticks per wave) and vector work (per probability
-// one v_exp_f32, half a v_pk_mul_f32, one or two halves of a v_cvt_pk_bf16_f32) however the two
-// are scheduled; the kernels keep the vector part at that minimum (both row constants ride in the
-// accumulators' initial values, the softmax scale is folded into an operand once per kernel).
+// What bounds them (tools/micro/attn_stamp.hip, s_memtime per phase of the dQ kernel, B 64 / H 20 / T 1024):
+// a 64-key tile costs a wave ~3,300 cycles with a second wave beside it on the SIMD — score chains 1,270 (16
+// MFMAs = 512 cycles of matrix pipe), softmax gradient 600, dQ accumulation 320, waiting for and storing the
+// next tile 400-500, barrier 290-560 — and a workgroup pays 7-8,000 cycles of prologue (fragment loads, delta)
+// and 2,600 of epilogue around on average nine tiles: the matrix pipe is busy 25-29 % of the time.
+// The structural limit is the LDS port, not the vector ALU: with 32 queries (or keys) per wave every MFMA takes a
+// fresh 1-KiB A fragment from LDS, 32 FLOPs per LDS byte, which is exactly what the CU's 128 B/cycle port
+// delivers at the four matrix pipes' full rate; 24 KiB of fragment reads per wave and tile keep the port ~55 %
+// busy at today's speed. Halving the bytes per FLOP takes 64 rows per wave, i.e. one wave per SIMD with the
+// whole register file and a hand-placed instruction stream. A first such dK/dV kernel (two 32-key blocks per
+// wave, score chains as VGPR-form inline-asm MFMAs, K / V operands in AGPRs) was correct and 15 % slower than
+// the kernel below in its straightforward form; its interleaved form did not survive the compiler's register
+// allocation (16-register accumulator tuples stay live whole, 28 spills). Not shipped; the analysis stands.
+// The kernels keep the vector part small: both row constants ride in the accumulators' initial values and the
+// softmax scale is folded into an operand once per kernel, so a probability costs one v_exp_f32, half a packed
+// multiply and one or two halves of a v_cvt_pk_bf16_f32.
 #include "attention_common.h"
 #include "pda_kernels.h"
 
@@ -51,6 +59,15 @@ constexpr int kThreads = 256;
 constexpr int kBM = 128;  // rows owned by a workgroup (queries in dq, keys in dkv)
 constexpr int kBN = 64;   // rows per streamed tile (keys in dq, queries in dkv)
 
+// Phase stamps of the dQ kernel (tools/micro/attn_stamp.hip): s_memtime around the phases of every tile,
+// summed per wave. Compiled out of the shipped kernel.
+#ifdef PDA_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[8192 * 4 * 10];
+#define PDA_ASTAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define PDA_ASTAMP(x)
+#endif
+
 // ============================================================================ dQ
 // amdgpu_waves_per_eu: with a register budget of at most 256 per wave the compiler keeps MFMA
 // accumulators in ordinary VGPRs. Left at the launch-bounds default (one wave per SIMD, 512
@@ -66,6 +83,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   constexpr int kDBlocks = D / 32;
   constexpr int kTileBytes = kBN * D * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+#ifdef PDA_ATTN_STAMPS
+  unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, s_p1 = 0, s_valu = 0, s_p2 = 0, s_store = 0, s_bar = 0, n_done = 0;
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,6 +107,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   const int q0 = qt * kBM + wave * 32;
   const int q_row = q0 + r;
   const int q_ld = q_row < T ? q_row : T - 1;
+
+  // The first key tile's loads go out before anything that waits for data, so that their latency runs beside
+  // that of the fragment loads below instead of behind it.
+  TileStager<D, kBN, kThreads> k_stage, v_stage;
+  k_stage.load(k_base, tok_stride, 0, T - 1, tid);
+  v_stage.load(v_base, tok_stride, 0, T - 1, tid);
 
   // Q and dO fragments (B operands), and delta = sum_d dO * O for this lane's query.
   bf16x8 qf[kKSteps], dof[kKSteps];
@@ -126,17 +153,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   const int wave_last_tile = min(q0 + 31, T - 1) / kBN;
   const bool wave_active = q0 < T;
 
-  TileStager<D, kBN, kThreads> k_stage, v_stage;
-  k_stage.load(k_base, tok_stride, 0, T - 1, tid);
-  v_stage.load(v_base, tok_stride, 0, T - 1, tid);
   k_stage.store(smem, tid);
   v_stage.store(smem + kTileBytes, tid);
   __syncthreads();
+#ifdef PDA_ATTN_STAMPS
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int j = 0; j < n_tiles; ++j) {
     const char* k_tile = smem + (j & 1) * 2 * kTileBytes;
     const char* v_tile = k_tile + kTileBytes;
     const bool has_next = j + 1 < n_tiles;
+    PDA_ASTAMP(ta);
     if (has_next) {
       k_stage.load(k_base, tok_stride, (j + 1) * kBN, T - 1, tid);
       v_stage.load(v_base, tok_stride, (j + 1) * kBN, T - 1, tid);
@@ -145,23 +173,46 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
     if (wave_active && j <= wave_last_tile) {  // wave-uniform
       f32x16 s_acc[2], dp_acc[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           s_acc[kb][i] = -lse2;    // row constants preloaded: the chains end as c S - LSE log2 e
           dp_acc[kb][i] = -delta;  // and dP - delta
         }
+      // The 2 x 2 x kKSteps operand fragments are requested a whole half-tile ahead of the MFMA that takes them
+      // (the first half's before any MFMA, the second half's one behind each MFMA of the first), so the matrix
+      // pipe runs its 4 kKSteps products back to back instead of waiting out an LDS round trip before each one.
+      bf16x8 frag[2][2 * kKSteps];
+      auto request = [&](int kb, int i) {
+        const char* tile = i < kKSteps ? k_tile : v_tile;
+        frag[kb][i] = lds_read_b128(tile, tile_off<D>(kb * 32 + r, 2 * (i % kKSteps) + h));
+      };
+      auto multiply = [&](int kb, int i) {
+        if (i < kKSteps) s_acc[kb] = mfma32(frag[kb][i], qf[i], s_acc[kb]);
+        else dp_acc[kb] = mfma32(frag[kb][i], dof[i - kKSteps], dp_acc[kb]);
+      };
 #pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) {
-          const bf16x8 kf = lds_read_b128(k_tile, tile_off<D>(kb * 32 + r, 2 * ks + h));
-          s_acc[kb] = mfma32(kf, qf[ks], s_acc[kb]);
-        }
+      for (int i = 0; i < 2 * kKSteps; ++i) request(0, i);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef PDA_ATTN_PRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) {
-          const bf16x8 vf = lds_read_b128(v_tile, tile_off<D>(kb * 32 + r, 2 * ks + h));
-          dp_acc[kb] = mfma32(vf, dof[ks], dp_acc[kb]);
-        }
+      for (int i = 0; i < 2 * kKSteps; ++i) {
+        multiply(0, i);
+        request(1, i);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int i = 0; i < 2 * kKSteps; ++i) multiply(1, i);
+#ifdef PDA_ATTN_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef PDA_ATTN_STAMPS
+      asm volatile("" : "+v"(s_acc[0]), "+v"(s_acc[1]), "+v"(dp_acc[0]), "+v"(dp_acc[1]));  // the chains' results exist
+      PDA_ASTAMP(tb);
+#endif
       const int key0 = j * kBN;
       const bool diag = key0 + kBN - 1 > q0;  // wave-uniform
       // dS^T = P^T (dP^T - delta), without the softmax scale. Two elements per packed fp32
@@ -200,6 +251,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       }
       if (__builtin_expect(diag, 0)) softmax_grad(std::true_type{});
       else softmax_grad(std::false_type{});
+#ifdef PDA_ATTN_STAMPS
+      asm volatile("" : "+v"(s_acc[0]), "+v"(s_acc[1]));
+      PDA_ASTAMP(tc);
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const f32x16& a = s_acc[s >> 1];
@@ -211,15 +266,30 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
           dq_acc[db] = mfma32(ktf, dsf, dq_acc[db]);
         }
       }
+#ifdef PDA_ATTN_STAMPS
+      PDA_ASTAMP(td);
+      s_p1 += tb - ta, s_valu += tc - tb, s_p2 += td - tc, ++n_done;
+#endif
     }
+#ifdef PDA_ATTN_STAMPS
+    else { PDA_ASTAMP(td); }
+#endif
 
     if (has_next) {
       char* nk = smem + ((j + 1) & 1) * 2 * kTileBytes;
       k_stage.store(nk, tid);
       v_stage.store(nk + kTileBytes, tid);
     }
+    PDA_ASTAMP(te);
     __syncthreads();
+#ifdef PDA_ATTN_STAMPS
+    PDA_ASTAMP(tf);
+    s_store += te - td, s_bar += tf - te;
+#endif
   }
+#ifdef PDA_ATTN_STAMPS
+  const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
   if (q_row < T) {
     bf16_raw* dq_row = dqkv + (int64_t(b) * T + q_row) * tok_stride + int64_t(head) * D;
@@ -232,6 +302,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
         *reinterpret_cast<u32x2*>(dq_row + db * 32 + 8 * g + 4 * h) = w;
       }
   }
+#ifdef PDA_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && blockIdx.x < 8192) {
+    unsigned long long* g = g_attn_stamps + (blockIdx.x * 4 + wave) * 10;
+    g[0] = t_loop - t_start, g[1] = s_p1, g[2] = s_valu, g[3] = s_p2, g[4] = s_store, g[5] = s_bar;
+    g[6] = t_end - t_loop_end, g[7] = n_done, g[8] = t_loop_end - t_loop, g[9] = (unsigned long long)qt;
+  }
+#endif
 }
 
 // ========================================================================= dK / dV
@@ -280,9 +359,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
   for (int ks = 0; ks < kKSteps; ++ks) {
     kf[ks] = *reinterpret_cast<const bf16x8*>(k_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
     vf[ks] = *reinterpret_cast<const bf16x8*>(v_base + int64_t(key_ld) * tok_stride + 16 * ks + 8 * h);
+  }
+  // The first query tile's loads go out before the scaling below waits for K: the two latencies overlap.
+  const int first_tile = (kt * kBM) / kBN;
+  const int n_tiles = (T + kBN - 1) / kBN;
+  const float* rowc_src = tid < 64 ? lse_row : delta_row;
+  const float rowc_mul = tid < 64 ? -kLog2e : -1.f;
+  auto load_rowc = [&](int tile) -> float {
+    if (tid >= 128) return 0.f;
+    int q = tile * kBN + (tid & 63);
+    q = q < T ? q : T - 1;
+    return rowc_src[q];
+  };
+  TileStager<D, kBN, kThreads> q_stage, do_stage;
+  q_stage.load(q_base, tok_stride, first_tile * kBN, T - 1, tid);
+  do_stage.load(do_base, o_stride, first_tile * kBN, T - 1, tid);
+  float rc_stage = load_rowc(first_tile);
+#pragma unroll
+  for (int ks = 0; ks < kKSteps; ++ks)
 #pragma unroll
     for (int e = 0; e < 8; ++e) kf[ks][e] = (__bf16)((float)kf[ks][e] * c);
-  }
   // Pin the arrival of the K / V fragments before the tile loop: waited for at their first use
   // inside it, the wait lands at the loop header, where the compiler cannot tell them from the
   // next tile's prefetch and waits for every outstanding load before the MFMAs of each tile.
@@ -300,26 +396,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(D == 6
       dv_acc[i][j] = 0.f;
     }
 
-  // Query tiles: from the one holding the workgroup's first key to the end.
-  const int first_tile = (kt * kBM) / kBN;
-  const int n_tiles = (T + kBN - 1) / kBN;
-
-  // Threads 0..63 stage -LSE log2 e, threads 64..127 stage -delta of the tile's 64 queries. The
-  // load returns the raw value and the arithmetic happens when it is written to LDS a tile later:
-  // computing at load time makes the compiler wait for the load — and, the counter being in
-  // order, for the tile loads issued just before it — at the top of every iteration.
-  const float* rowc_src = tid < 64 ? lse_row : delta_row;
-  const float rowc_mul = tid < 64 ? -kLog2e : -1.f;
-  auto load_rowc = [&](int tile) -> float {
-    if (tid >= 128) return 0.f;
-    int q = tile * kBN + (tid & 63);
-    q = q < T ? q : T - 1;
-    return rowc_src[q];
-  };
-  TileStager<D, kBN, kThreads> q_stage, do_stage;
-  q_stage.load(q_base, tok_stride, first_tile * kBN, T - 1, tid);
-  do_stage.load(do_base, o_stride, first_tile * kBN, T - 1, tid);
-  float rc_stage = load_rowc(first_tile);
   q_stage.store(smem, tid);
   do_stage.store(smem + kTileBytes, tid);
   if (tid < 128) rowc[tid] = rc_stage * rowc_mul;
