@@ -16,6 +16,7 @@ sharded models can be saved (a rank-0-only ``state_dict()`` deadlocks under shar
 from __future__ import annotations
 
 import os
+import struct
 from typing import Any, Optional
 
 import torch
@@ -32,11 +33,12 @@ class DistributedTrainer(Trainer):
                  max_steps: int = 1000, global_batch_size: int = 32, micro_batch_size: int = 8,
                  log_every_n_steps: int = 10, save_every_n_steps: Optional[int] = None,
                  checkpoint_dir: str = "checkpoints", ddp_enabled: bool = True,
-                 metrics_file: Optional[str] = None):
+                 metrics_file: Optional[str] = None, merge_micro_batches=1):
         super().__init__(model=model, optimizer=optimizer, lr_scheduler=lr_scheduler, max_steps=max_steps,
                          global_batch_size=global_batch_size, micro_batch_size=micro_batch_size,
                          log_every_n_steps=log_every_n_steps, save_every_n_steps=save_every_n_steps,
-                         checkpoint_dir=checkpoint_dir, metrics_file=metrics_file)
+                         checkpoint_dir=checkpoint_dir, metrics_file=metrics_file,
+                         merge_micro_batches=merge_micro_batches)
         self.ddp_enabled = ddp_enabled
         if ddp_enabled:
             if not comm.is_initialized():
@@ -66,21 +68,28 @@ class DistributedTrainer(Trainer):
                 with annotate("forward"):
                     loss = self._loss(inputs, targets)
                 with annotate("backward (no_sync)"):
-                    (loss / self.grad_accumulation_steps).backward()
+                    (loss * self._backward_scale()).backward()
         else:
             with annotate("forward"):
                 loss = self._loss(inputs, targets)
             with annotate("backward"):
-                (loss / self.grad_accumulation_steps).backward()
+                (loss * self._backward_scale()).backward()
         return loss.detach()
 
     def _run_micro_batch(self, inputs, targets, is_last_microbatch: bool) -> torch.Tensor:
         if not self.ddp_enabled:  # every micro-batch synchronises: gradients are read in between
             return self.training_step(inputs, targets, should_sync=True)
         # gradients are read only at the synchronising micro-batch: weight gradients once per window
-        accum = self.grad_accumulation_steps
-        with ops.accumulation_window(self.batch_count % accum, accum):
+        index, total = self._window_position()
+        with ops.accumulation_window(index, total):
             return self.training_step(inputs, targets, should_sync=is_last_microbatch)
+
+    def _agree_merge(self, merge: int) -> int:
+        """The ranks' smallest choice: every rank must run the same passes, or their collectives differ."""
+        c = comm.get_communicator() if self.ddp_enabled else None
+        if c is None or c.world_size == 1:
+            return merge
+        return min(struct.unpack("<q", blob)[0] for blob in c.exchange(struct.pack("<q", int(merge))))
 
     def _aggregate_loss(self, loss: float, device) -> float:
         """Mean of the ranks' window losses. Every rank calls this on logging steps."""

@@ -18,7 +18,16 @@ The loop itself is arranged for a GPU that should never wait for the host:
 * with :class:`~pytorch_distributed_amd.optim.FusedAdamW` the gradients are cleared
   inside the optimizer kernel;
 * throughput (tokens/s, MFU against the MI355X dense bf16 peak) is appended to the log
-  line and optionally written as JSON lines.
+  line and optionally written as JSON lines;
+* ``merge_micro_batches``: the micro-batch size of the reference's recipe (8 sequences) is a
+  memory limit of 80 GB devices, not part of the optimisation problem — the mean loss over 4 x 8
+  sequences and its gradient are the mean over 32. With 288 GB per GPU the trainer may therefore
+  run several of the loader's micro-batches as ONE forward / backward pass (larger GEMMs, one
+  weight-gradient product, one set of FSDP all-gathers per window instead of one per
+  micro-batch). ``"auto"`` runs the first window as given, measures what a micro-batch needs and
+  merges as many as fit from the second window on; an integer merges that many; 1 keeps the
+  loader's micro-batches. The optimizer sees the same gradient up to summation order; dropout
+  draws different masks (one Philox stream per pass).
 """
 from __future__ import annotations
 
@@ -49,7 +58,8 @@ class Trainer:
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, lr_scheduler: Optional[Any] = None,
                  max_steps: int = 1000, global_batch_size: int = 32, micro_batch_size: int = 8,
                  log_every_n_steps: int = 10, save_every_n_steps: Optional[int] = None,
-                 checkpoint_dir: str = "checkpoints", metrics_file: Optional[str] = None):
+                 checkpoint_dir: str = "checkpoints", metrics_file: Optional[str] = None,
+                 merge_micro_batches: Union[int, str] = 1):
         self.model = model
         self.optimizer = optimizer
         self.lr_scheduler = lr_scheduler
@@ -62,6 +72,12 @@ class Trainer:
         self.metrics_file = metrics_file
         self.world_size = 1
         self.rank = 0
+        self.merge_micro_batches = merge_micro_batches
+        self._merge = 1              # loader micro-batches per forward / backward pass
+        self._window_merge = 1       # ... in the window that is running (fixed at its first pass)
+        self._merged_now = 1         # ... in the pass that is running (smaller only when the loader ran out)
+        self._merge_pending = False  # "auto": still to be decided after the first window
+        self._pass_bytes = None      # what the first pass allocated above the resident state
 
         if global_batch_size % micro_batch_size != 0:
             raise ValueError(f"Global batch size ({global_batch_size}) must be divisible by "
@@ -101,14 +117,87 @@ class Trainer:
         with annotate("forward"):
             loss = self._loss(inputs, targets)
         with annotate("backward"):
-            (loss / self.grad_accumulation_steps).backward()
+            (loss * self._backward_scale()).backward()
         return loss.detach()
 
+    def _backward_scale(self) -> float:
+        """Weight of this pass's mean loss in the window's mean: its share of the window's micro-batches."""
+        return self._merged_now / self.grad_accumulation_steps
+
+    # ------------------------------------------------------------------ merged passes
+    def _requested_merge(self) -> Optional[int]:
+        """Micro-batches per pass asked for by ``merge_micro_batches``; None = decide by measurement."""
+        m, accum = self.merge_micro_batches, self.grad_accumulation_steps
+        if m in (None, False, 0, 1, "off", "1"):
+            return 1
+        if m in (True, "all", "on"):
+            return accum
+        if m == "auto":
+            return None
+        m = int(m)
+        if m < 1 or accum % m != 0:
+            raise ValueError(f"merge_micro_batches={m} must divide the {accum} micro-batches of a window")
+        return m
+
+    def _agree_merge(self, merge: int) -> int:
+        """Hook for the distributed trainer: every rank must run the same number of passes."""
+        return merge
+
+    def _decide_merge(self, device) -> None:
+        """"auto", after the first window: the largest divisor of the window whose passes fit the memory
+        that is free now (parameters, gradients and optimizer state are all allocated by then), with the
+        first pass's footprint as the measure and 15 % of the room left alone."""
+        self._merge_pending = False
+        accum, merge = self.grad_accumulation_steps, 1
+        room = 0
+        if device.type == "cuda" and accum > 1 and self._pass_bytes:
+            free, _total = torch.cuda.mem_get_info(device)
+            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+            room = 0.85 * (free + cached)
+            for cand in range(accum, 1, -1):
+                if accum % cand == 0 and cand * self._pass_bytes * 1.1 <= room:
+                    merge = cand
+                    break
+        self._merge = self._agree_merge(merge)
+        if self.rank == 0 and accum > 1:
+            what = (f"{accum // self._merge} pass(es) of {self._merge * self.micro_batch_size} sequences"
+                    if self._merge > 1 else "given (no merge)")
+            print(f"Accumulation window of {accum} x {self.micro_batch_size} sequences runs as {what} "
+                  f"[one micro-batch needs {(self._pass_bytes or 0) / 2**30:.1f} GiB, {room / 2**30:.0f} GiB usable]",
+                  flush=True)
+
+    def _passes(self, batches):
+        """The loader's micro-batches grouped into passes: ``(inputs, targets, n)`` with ``n`` micro-batches
+        concatenated along the batch dimension, never across the end of an accumulation window and never
+        drawn from the loader before the pass is due (a checkpoint written after a step sees the loader
+        exactly ``batch_count`` batches in)."""
+        it = iter(batches)
+        accum = self.grad_accumulation_steps
+        self._window_merge = 1  # a window entered in its middle (resumed there) runs as the loader gives it
+        while self.current_step < self.max_steps:
+            if self.batch_count % accum == 0:
+                self._window_merge = self._merge
+            group = []
+            for _ in range(self._window_merge):
+                nxt = next(it, None)
+                if nxt is None:
+                    break
+                group.append(nxt)
+            if not group:
+                return
+            if len(group) == 1:
+                yield group[0][0], group[0][1], 1
+            else:
+                yield torch.cat([g[0] for g in group]), torch.cat([g[1] for g in group]), len(group)
+
     # ------------------------------------------------------------------ helpers
-    def _accumulate_loss(self, loss: torch.Tensor) -> None:
+    def _accumulate_loss(self, loss: torch.Tensor, micro_batches: int = 1) -> None:
         if self.loss_accumulator is None:
             self.loss_accumulator = torch.zeros((), dtype=torch.float32, device=loss.device)
-        self.loss_accumulator += loss.float()
+        if micro_batches == 1:
+            self.loss_accumulator += loss.float()
+        else:  # a merged pass stands for that many micro-batch losses
+            self.loss_accumulator.add_(loss.float(), alpha=float(micro_batches))
 
     def _optimizer_step(self) -> None:
         with annotate("optimizer"):
@@ -238,19 +327,26 @@ class Trainer:
 
         self._dataloader = dataloader
         batches = self._resume_data(dataloader)
-        for inputs, targets in batches:
-            if self.current_step >= self.max_steps:
-                break
+        requested = self._requested_merge()
+        self._merge = 1 if requested is None else requested
+        self._merge_pending = requested is None and self.grad_accumulation_steps > 1
+        for inputs, targets, merged in self._passes(batches):
             device = inputs.device
             self._seq_len = inputs.shape[1]
             if self._time_of_last_log is None:
                 self._time_of_last_log = time.time()
+            measure = self._merge_pending and self._pass_bytes is None and device.type == "cuda"
+            if measure:  # allocator statistics are kept on the host: no synchronisation needed to read them
+                before = torch.cuda.memory_allocated(device)
 
-            is_last_microbatch = (self.batch_count + 1) % self.grad_accumulation_steps == 0
+            self._merged_now = merged
+            is_last_microbatch = (self.batch_count + merged) % self.grad_accumulation_steps == 0
             loss = self._run_micro_batch(inputs, targets, is_last_microbatch)
-            self._accumulate_loss(loss)
+            self._accumulate_loss(loss, merged)
             self._tokens_since_log += inputs.numel() * self.world_size
-            self.batch_count += 1
+            self.batch_count += merged
+            if measure:
+                self._pass_bytes = max(1, torch.cuda.max_memory_allocated(device) - before)
 
             if is_last_microbatch:
                 self._optimizer_step()
@@ -260,6 +356,8 @@ class Trainer:
                 self.loss_accumulator.zero_()
                 self.current_step += 1
                 self._maybe_checkpoint()
+                if self._merge_pending:
+                    self._decide_merge(device)
 
             if profiler is not None:
                 profiler.step()
@@ -276,13 +374,18 @@ class Trainer:
         # Nobody reads a gradient before the window's last backward (no_sync in between), so the linear
         # layers may keep the earlier micro-batches' operands and form each weight gradient once, as one
         # long product over the whole window (ops.linear.accumulation_window).
-        accum = self.grad_accumulation_steps
+        index, total = self._window_position()
         no_sync = getattr(self.model, "no_sync", None)
-        with ops.accumulation_window(self.batch_count % accum, accum):
+        with ops.accumulation_window(index, total):
             if no_sync is not None and not is_last_microbatch:
                 with no_sync():
                     return self.training_step(inputs, targets)
             return self.training_step(inputs, targets)
+
+    def _window_position(self) -> tuple:
+        """(index, count) of the running pass among the passes of its accumulation window."""
+        accum, merge = self.grad_accumulation_steps, self._window_merge
+        return (self.batch_count % accum) // merge, accum // merge
 
     # ------------------------------------------------------------------ data position
     def _data_state(self) -> dict:

@@ -58,7 +58,17 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
                     help="dtype in which the micro-batches of an accumulation window are "
                          "summed; auto = fp32 when bf16 gradients are accumulated over more than one micro-batch "
                          "(the reference accumulates in fp32), the parameter dtype otherwise")
+    ap.add_argument("--merge-micro-batches", default="auto",
+                    help="auto | off | all | N: run N of the loader's micro-batches as one forward / backward pass "
+                         "(same optimizer step up to summation order, larger GEMMs, fewer collectives); auto = as "
+                         "many as the memory left after the first window holds (GPU only)")
     return ap
+
+
+def resolve_merge(args):
+    """``--merge-micro-batches`` as the trainers' ``merge_micro_batches`` argument."""
+    m = str(getattr(args, "merge_micro_batches", "off")).lower()
+    return m if m in ("auto", "off", "all") else int(m)
 
 
 def resolve_grad_accum_dtype(args, dtype, world_size: int = 1) -> str:

@@ -68,16 +68,18 @@ def test_bench_reports_the_reference_recipe_next_to_the_headline():
     assert ref["global_batch"] == 32 and ref["micro_batch"] == 8 and ref["grad_accum"] == 4
     assert ref["activation_checkpoint"] == "selective" and ref["steps"] == 2
     assert abs(ref["value"] - 32 * 1024 / (ref["ms_per_step"] / 1e3)) < 1e-6 * ref["value"]
+    merged = ref["merged_window"]  # the same 32 sequences as one pass: what the trainers do when memory allows
+    assert abs(merged["value"] - 32 * 1024 / (merged["ms_per_step"] / 1e3)) < 1e-6 * merged["value"]
 
 
 def test_train_baseline_script_accumulates_in_fp32_buffers_and_defers_weight_gradients():
     """The single-GPU script at its own recipe shape (4 micro-batches per step) on a small model: with the
     fp32 accumulation buffers and one weight-gradient product per window it logs the same losses as with
     bf16 accumulation and a product per micro-batch (same seed, same synthetic tokens)."""
-    def run(extra, env_extra):
+    def run(extra, env_extra, merge="off"):
         proc = subprocess.run([sys.executable, "train_baseline.py", "--synthetic-data", "--model", "gpt2", "--max-steps", "6",
                                "--log-every", "1", "--no-profile", "--global-batch-size", "16", "--micro-batch-size", "4",
-                               "--sequence-length", "256", "--dropout", "0", *extra],
+                               "--sequence-length", "256", "--dropout", "0", "--merge-micro-batches", merge, *extra],
                               cwd=ROOT, env=dict(os.environ, **env_extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True, timeout=170)
         assert proc.returncode == 0, proc.stderr[-2000:]
@@ -91,3 +93,7 @@ def test_train_baseline_script_accumulates_in_fp32_buffers_and_defers_weight_gra
     assert "Gradient accumulation in fp32 buffers" not in out_old
     assert max(abs(a - b) for a, b in zip(new, old)) < 3e-2, (new, old)
     assert all(10.0 < v < 11.5 for v in new), new  # random tokens: the loss stays near ln(vocabulary)
+    # the scripts' default: from the second window on the 4 micro-batches run as one pass of 16 sequences
+    auto, out_auto = run([], {}, merge="auto")
+    assert "runs as 1 pass(es) of 16 sequences" in out_auto, out_auto[-1500:]
+    assert max(abs(a - b) for a, b in zip(new, auto)) < 3e-2, (new, auto)

@@ -118,11 +118,14 @@ def _sharded_checkpoint(rank, world, tmp):
         m(x[rank * 2:rank * 2 + 2], y[rank * 2:rank * 2 + 2]).backward()
         o.step(zero_grad=True)
     a, b = wrapped.state_dict(), wrapped2.state_dict()
-    worst = max((a[k].float() - b[k].float()).abs().max().item() for k in a)
+    diffs = [(a[k].float() - b[k].float()).abs() for k in a]
+    worst = max(d.max().item() for d in diffs)
+    mean = sum(d.sum().item() for d in diffs) / sum(d.numel() for d in diffs)
     # The optimizer state came along: a step from the restored state lands where the original lands. Not
-    # bit for bit on the GPU — the library's stream-K GEMMs do not sum in a fixed order — but within one
-    # bf16 rounding of a parameter; a lost moment or step count would show as a full lr-sized step (1e-3).
-    assert worst <= 2.5e-4, worst
+    # bit for bit on the GPU — the library's stream-K GEMMs do not sum in a fixed order, and AdamW turns a
+    # gradient at rounding level into a step of either sign, so single elements may differ by up to 2 x lr.
+    # A lost moment or step count moves EVERY element by a sizeable part of lr (1e-3): the mean tells.
+    assert worst <= 2.0e-3 and mean <= 2.0e-5, (worst, mean)
 
 
 def test_sharded_checkpoint_round_trip_at_two_ranks_on_one_gpu(tmp_path, monkeypatch):
@@ -174,3 +177,5 @@ def test_bench_and_train_scripts_with_two_ranks_on_one_shared_gpu(tmp_path):
         losses = [float(ln.split("loss=")[1].split()[0]) for ln in p.stdout.splitlines() if "loss=" in ln]
         assert len(losses) == 3 and all(10.0 < v < 11.5 for v in losses), p.stdout[-1500:]
         assert "world_size=2" in p.stdout and "c10d:gloo" in p.stdout
+        # the two ranks agreed to run the second window's 2 micro-batches of 4 as one pass
+        assert "runs as 1 pass(es) of 8 sequences" in p.stdout, p.stdout[-1500:]
