@@ -3,6 +3,8 @@ the same learnable synthetic stream three ways —
 
   hip-bf16   every HIP kernel of this package (the path bench.py measures)
   ref-bf16   the PyTorch reference ops in bf16 (PDA_FORCE_REFERENCE=1)
+  hip-accum  the same kernels with every batch split into ``--accum`` micro-batches inside an
+             accumulation window (weight gradients formed once per window from the kept operands)
   ref-fp32   the PyTorch reference ops in fp32 (the reference repo's precision)
 
 and prints the loss curves side by side. The data is a first-order Markov chain over 128 token
@@ -40,7 +42,7 @@ def markov_batches(steps, batch, seq_len, device, seed=7, states=1024, fanout=4)
     return out
 
 
-def train(name, cls, cfg, init, batches, lr, dtype, reference):
+def train(name, cls, cfg, init, batches, lr, dtype, reference, accum=1):
     if reference:
         os.environ["PDA_FORCE_REFERENCE"] = "1"
     else:
@@ -51,12 +53,21 @@ def train(name, cls, cfg, init, batches, lr, dtype, reference):
     opt = FusedAdamW(model.parameters(), lr=lr, weight_decay=0.1)
     sched = CosineAnnealingLR(opt, T_max=len(batches), eta_min=0.1 * lr)
     losses = []
+    from pytorch_distributed_amd import ops
     for x in batches:
-        loss = model(x[:, :-1], x[:, 1:])
-        loss.backward()
+        if accum == 1:
+            loss = model(x[:, :-1], x[:, 1:])
+            loss.backward()
+        else:
+            loss = 0.0
+            for i, part in enumerate(x.chunk(accum)):
+                with ops.accumulation_window(i, accum):
+                    piece = model(part[:, :-1], part[:, 1:]) / accum
+                    piece.backward()
+                loss = loss + piece.detach()
         opt.step(zero_grad=True)
         sched.step()
-        losses.append(loss.detach())
+        losses.append(loss.detach() if accum == 1 else loss)
     os.environ.pop("PDA_FORCE_REFERENCE", None)
     return name, torch.stack(losses).float().cpu()
 
@@ -68,6 +79,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--lr", type=float, default=6e-4)
+    ap.add_argument("--accum", type=int, default=4, help="micro-batches per step of the hip-accum run")
     ap.add_argument("--states", type=int, default=128, help="token ids the Markov chain visits")
     ap.add_argument("--arch", choices=["gpt2", "llama"], default="gpt2",
                     help="llama: RMSNorm / rotary / SwiGLU blocks, d = 512, four heads of 128")
@@ -82,6 +94,7 @@ def main():
     init = {k: v.clone() for k, v in cls(cfg).state_dict().items()}
     batches = markov_batches(a.steps, a.batch, a.seq_len, "cuda", states=a.states)
     runs = [train("hip-bf16", cls, cfg, init, batches, a.lr, torch.bfloat16, False),
+            train("hip-accum", cls, cfg, init, batches, a.lr, torch.bfloat16, False, accum=a.accum),
             train("ref-bf16", cls, cfg, init, batches, a.lr, torch.bfloat16, True),
             train("ref-fp32", cls, cfg, init, batches, a.lr, torch.float32, True)]
     print(f"{a.arch} {a.layers} layers d={cfg.n_embd}, batch {a.batch} x {a.seq_len}, {a.steps} steps, "
@@ -103,11 +116,11 @@ def main():
     print("first step with loss < 2.0: " + ", ".join(f"{n} {v}" for n, v in cross.items()))
     floor = math.log(4)
     ref_tail = min(tail["ref-bf16"], tail["ref-fp32"])
-    ref_cross = [v for k, v in cross.items() if k != "hip-bf16" and v is not None]
-    # Pass: the HIP run ends within 2 % of the better reference and 5 % of the entropy floor, and
+    ref_cross = [v for k, v in cross.items() if k.startswith("ref-") and v is not None]
+    # Pass: each HIP run ends within 2 % of the better reference and 5 % of the entropy floor, and
     # leaves the plateau no later than 1.5x the slower reference.
-    ok = (tail["hip-bf16"] < 1.02 * ref_tail and tail["hip-bf16"] < 1.05 * floor and cross["hip-bf16"] is not None
-          and bool(ref_cross) and cross["hip-bf16"] <= 1.5 * max(ref_cross))
+    ok = all(tail[n] < 1.02 * ref_tail and tail[n] < 1.05 * floor and cross[n] is not None
+             and bool(ref_cross) and cross[n] <= 1.5 * max(ref_cross) for n in ("hip-bf16", "hip-accum"))
     print("CONVERGENCE", "OK" if ok else "MISMATCH")
     sys.exit(0 if ok else 1)
 
