@@ -160,3 +160,17 @@ def _distributed_merge(rank, world, wrapper):
 @pytest.mark.parametrize("wrapper", ["ddp", "fsdp"])
 def test_merged_passes_under_data_parallel_wrappers(wrapper):
     run_distributed(_distributed_merge, world=2, args=(wrapper,))
+
+
+def test_cli_flag_values():
+    import argparse
+
+    from pytorch_distributed_amd.utils import cli
+
+    ap = cli.add_common_args(argparse.ArgumentParser())
+    assert cli.resolve_merge(ap.parse_args([])) == "auto"            # the scripts' default
+    assert cli.resolve_merge(ap.parse_args(["--merge-micro-batches", "off"])) == "off"
+    assert cli.resolve_merge(ap.parse_args(["--merge-micro-batches", "ALL"])) == "all"
+    assert cli.resolve_merge(ap.parse_args(["--merge-micro-batches", "2"])) == 2
+    with pytest.raises(ValueError):
+        cli.resolve_merge(ap.parse_args(["--merge-micro-batches", "some"]))
