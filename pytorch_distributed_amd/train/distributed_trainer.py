@@ -33,12 +33,12 @@ class DistributedTrainer(Trainer):
                  max_steps: int = 1000, global_batch_size: int = 32, micro_batch_size: int = 8,
                  log_every_n_steps: int = 10, save_every_n_steps: Optional[int] = None,
                  checkpoint_dir: str = "checkpoints", ddp_enabled: bool = True,
-                 metrics_file: Optional[str] = None, merge_micro_batches=1):
+                 metrics_file: Optional[str] = None, merge_micro_batches=1, relax_recompute: bool = False):
         super().__init__(model=model, optimizer=optimizer, lr_scheduler=lr_scheduler, max_steps=max_steps,
                          global_batch_size=global_batch_size, micro_batch_size=micro_batch_size,
                          log_every_n_steps=log_every_n_steps, save_every_n_steps=save_every_n_steps,
                          checkpoint_dir=checkpoint_dir, metrics_file=metrics_file,
-                         merge_micro_batches=merge_micro_batches)
+                         merge_micro_batches=merge_micro_batches, relax_recompute=relax_recompute)
         self.ddp_enabled = ddp_enabled
         if ddp_enabled:
             if not comm.is_initialized():
@@ -84,12 +84,13 @@ class DistributedTrainer(Trainer):
         with ops.accumulation_window(index, total):
             return self.training_step(inputs, targets, should_sync=is_last_microbatch)
 
-    def _agree_merge(self, merge: int) -> int:
-        """The ranks' smallest choice: every rank must run the same passes, or their collectives differ."""
+    def _agree(self, merge: int, relax: bool) -> tuple:
+        """The ranks' smallest choices: every rank must run the same passes, or their collectives differ."""
         c = comm.get_communicator() if self.ddp_enabled else None
         if c is None or c.world_size == 1:
-            return merge
-        return min(struct.unpack("<q", blob)[0] for blob in c.exchange(struct.pack("<q", int(merge))))
+            return merge, relax
+        votes = [struct.unpack("<qq", blob) for blob in c.exchange(struct.pack("<qq", int(merge), int(relax)))]
+        return min(v[0] for v in votes), all(v[1] for v in votes)
 
     def _aggregate_loss(self, loss: float, device) -> float:
         """Mean of the ranks' window losses. Every rank calls this on logging steps."""

@@ -27,7 +27,11 @@ The loop itself is arranged for a GPU that should never wait for the host:
   micro-batch). ``"auto"`` runs the first window as given, measures what a micro-batch needs and
   merges as many as fit from the second window on; an integer merges that many; 1 keeps the
   loader's micro-batches. The optimizer sees the same gradient up to summation order; dropout
-  draws different masks (one Philox stream per pass).
+  draws different masks (one Philox stream per pass);
+* ``relax_recompute``: selective activation recomputation exists to save memory and returns
+  bit-identical gradients, so a model built with ``activation_checkpoint="selective"`` is switched
+  to ``"none"`` after the first window when the same measurement says twice the footprint still
+  fits (decided together with the merge, agreed between ranks).
 """
 from __future__ import annotations
 
@@ -59,7 +63,7 @@ class Trainer:
                  max_steps: int = 1000, global_batch_size: int = 32, micro_batch_size: int = 8,
                  log_every_n_steps: int = 10, save_every_n_steps: Optional[int] = None,
                  checkpoint_dir: str = "checkpoints", metrics_file: Optional[str] = None,
-                 merge_micro_batches: Union[int, str] = 1):
+                 merge_micro_batches: Union[int, str] = 1, relax_recompute: bool = False):
         self.model = model
         self.optimizer = optimizer
         self.lr_scheduler = lr_scheduler
@@ -73,6 +77,7 @@ class Trainer:
         self.world_size = 1
         self.rank = 0
         self.merge_micro_batches = merge_micro_batches
+        self.relax_recompute = relax_recompute
         self._merge = 1              # loader micro-batches per forward / backward pass
         self._window_merge = 1       # ... in the window that is running (fixed at its first pass)
         self._merged_now = 1         # ... in the pass that is running (smaller only when the loader ran out)
@@ -139,32 +144,64 @@ class Trainer:
             raise ValueError(f"merge_micro_batches={m} must divide the {accum} micro-batches of a window")
         return m
 
-    def _agree_merge(self, merge: int) -> int:
+    def _agree(self, merge: int, relax: bool) -> tuple:
         """Hook for the distributed trainer: every rank must run the same number of passes."""
-        return merge
+        return merge, relax
+
+    @staticmethod
+    def _free_bytes(device) -> int:
+        """Device memory a new allocation can still get (free at the driver plus cached by the allocator)."""
+        if device.type != "cuda":
+            return 0
+        free, _total = torch.cuda.mem_get_info(device)
+        return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+
+    @staticmethod
+    def _allocated_now(device) -> Optional[int]:
+        """Bytes allocated on ``device`` now (allocator statistics live on the host: no synchronisation)."""
+        return torch.cuda.memory_allocated(device) if device.type == "cuda" else None
+
+    @staticmethod
+    def _allocated_peak(device) -> int:
+        return torch.cuda.max_memory_allocated(device)
+
+    def _recompute_owner(self):
+        """The module whose ``activation_checkpoint`` attribute sets the model's policy, or None."""
+        owner = getattr(unwrap_model(self.model), "transformer", None)
+        return owner if isinstance(getattr(owner, "activation_checkpoint", None), str) else None
 
     def _decide_merge(self, device) -> None:
-        """"auto", after the first window: the largest divisor of the window whose passes fit the memory
-        that is free now (parameters, gradients and optimizer state are all allocated by then), with the
-        first pass's footprint as the measure and 15 % of the room left alone."""
-        self._merge_pending = False
-        accum, merge = self.grad_accumulation_steps, 1
-        room = 0
-        if device.type == "cuda" and accum > 1 and self._pass_bytes:
-            free, _total = torch.cuda.mem_get_info(device)
-            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-            room = 0.85 * (free + cached)
-            for cand in range(accum, 1, -1):
-                if accum % cand == 0 and cand * self._pass_bytes * 1.1 <= room:
-                    merge = cand
-                    break
-        self._merge = self._agree_merge(merge)
-        if self.rank == 0 and accum > 1:
-            what = (f"{accum // self._merge} pass(es) of {self._merge * self.micro_batch_size} sequences"
-                    if self._merge > 1 else "given (no merge)")
-            print(f"Accumulation window of {accum} x {self.micro_batch_size} sequences runs as {what} "
-                  f"[one micro-batch needs {(self._pass_bytes or 0) / 2**30:.1f} GiB, {room / 2**30:.0f} GiB usable]",
-                  flush=True)
+        """After the first window: the largest divisor of the window whose passes fit the memory that is
+        free now (parameters, gradients and optimizer state are all allocated by then), with the first
+        pass's footprint as the measure and 15 % of the room left alone; and whether the selective
+        recomputation can be dropped on top of that (its activations: taken as twice the footprint)."""
+        decide_merge, self._merge_pending = self._merge_pending, False
+        accum, merge, relax, room = self.grad_accumulation_steps, self._merge, False, 0
+        if self._pass_bytes:
+            room = 0.85 * self._free_bytes(device)
+            if decide_merge:
+                merge = 1
+                for cand in range(accum, 1, -1):
+                    if accum % cand == 0 and cand * self._pass_bytes * 1.1 <= room:
+                        merge = cand
+                        break
+            owner = self._recompute_owner()
+            relax = (self.relax_recompute and owner is not None and owner.activation_checkpoint == "selective"
+                     and merge * self._pass_bytes * 1.1 * 2.0 <= room)
+        merge, relax = self._agree(merge, relax)
+        self._merge = merge
+        if relax:
+            self._recompute_owner().activation_checkpoint = "none"
+        if self.rank == 0:
+            measured = f"[one micro-batch needs {(self._pass_bytes or 0) / 2**30:.1f} GiB, {room / 2**30:.0f} GiB usable]"
+            if decide_merge and accum > 1:
+                what = (f"{accum // merge} pass(es) of {merge * self.micro_batch_size} sequences"
+                        if merge > 1 else "given (no merge)")
+                print(f"Accumulation window of {accum} x {self.micro_batch_size} sequences runs as {what} {measured}",
+                      flush=True)
+            if relax:
+                print(f"Selective activation recomputation switched off: everything is kept for backward {measured}",
+                      flush=True)
 
     def _passes(self, batches):
         """The loader's micro-batches grouped into passes: ``(inputs, targets, n)`` with ``n`` micro-batches
@@ -330,14 +367,13 @@ class Trainer:
         requested = self._requested_merge()
         self._merge = 1 if requested is None else requested
         self._merge_pending = requested is None and self.grad_accumulation_steps > 1
+        tune_pending = self._merge_pending or (self.relax_recompute and self._recompute_owner() is not None)
         for inputs, targets, merged in self._passes(batches):
             device = inputs.device
             self._seq_len = inputs.shape[1]
             if self._time_of_last_log is None:
                 self._time_of_last_log = time.time()
-            measure = self._merge_pending and self._pass_bytes is None and device.type == "cuda"
-            if measure:  # allocator statistics are kept on the host: no synchronisation needed to read them
-                before = torch.cuda.memory_allocated(device)
+            before = self._allocated_now(device) if tune_pending and self._pass_bytes is None else None
 
             self._merged_now = merged
             is_last_microbatch = (self.batch_count + merged) % self.grad_accumulation_steps == 0
@@ -345,8 +381,8 @@ class Trainer:
             self._accumulate_loss(loss, merged)
             self._tokens_since_log += inputs.numel() * self.world_size
             self.batch_count += merged
-            if measure:
-                self._pass_bytes = max(1, torch.cuda.max_memory_allocated(device) - before)
+            if before is not None:
+                self._pass_bytes = max(1, self._allocated_peak(device) - before)
 
             if is_last_microbatch:
                 self._optimizer_step()
@@ -356,7 +392,8 @@ class Trainer:
                 self.loss_accumulator.zero_()
                 self.current_step += 1
                 self._maybe_checkpoint()
-                if self._merge_pending:
+                if tune_pending:
+                    tune_pending = False
                     self._decide_merge(device)
 
             if profiler is not None:

@@ -5,7 +5,10 @@ The reference hard-codes every hyper-parameter inside ``main()``
 The flags below default to exactly those literals (GPT-2 Large, global batch 32, micro
 batch 8, sequence length 1024, 20 steps, lr 3e-4, weight decay 0.1, cosine to 0.1 x lr, 10
 training shards, profiler schedule 2/2/6/1), so running a script without arguments is the
-reference's run; everything else is opt-in.
+reference's run; everything else is opt-in. Two defaults are decided by measured memory instead of
+being fixed: how many of a window's micro-batches run as one pass (``--merge-micro-batches auto``)
+and whether the selective recomputation is kept (``--activation-checkpoint auto``); neither changes
+the optimizer step beyond summation order, and ``off`` / ``selective`` restore the literal recipe.
 """
 from __future__ import annotations
 
@@ -53,7 +56,9 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
     ap.add_argument("--checkpoint-dir", default="checkpoints")
     ap.add_argument("--resume", default=None, help="checkpoint path, or 'latest' to pick the newest in --checkpoint-dir")
     ap.add_argument("--metrics-file", default=None)
-    ap.add_argument("--activation-checkpoint", choices=["selective", "full", "none"], default="selective")
+    ap.add_argument("--activation-checkpoint", choices=["auto", "selective", "full", "none"], default="auto",
+                    help="auto = the reference's selective recomputation, dropped after the first accumulation window "
+                         "when the measured memory says everything can be kept (same gradients bit for bit)")
     ap.add_argument("--grad-accum-dtype", choices=["auto", "param", "fp32"], default="auto",
                     help="dtype in which the micro-batches of an accumulation window are "
                          "summed; auto = fp32 when bf16 gradients are accumulated over more than one micro-batch "
@@ -63,6 +68,11 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
                          "(same optimizer step up to summation order, larger GEMMs, fewer collectives); auto = as "
                          "many as the memory left after the first window holds (GPU only)")
     return ap
+
+
+def model_activation_checkpoint(args) -> str:
+    """The policy the model is built with (``auto`` starts as the reference's ``selective``)."""
+    return "selective" if args.activation_checkpoint == "auto" else args.activation_checkpoint
 
 
 def resolve_merge(args):
@@ -97,9 +107,9 @@ def build_model(args, device, dtype):
     with init_on_device(device, dtype) if on_gpu else contextlib.nullcontext():
         if hasattr(cfg, "intermediate_size"):
             from ..models.llama import LlamaForCausalLM
-            model = LlamaForCausalLM(cfg, activation_checkpoint=args.activation_checkpoint)
+            model = LlamaForCausalLM(cfg, activation_checkpoint=model_activation_checkpoint(args))
         else:
-            model = MyGPT2LMHeadModel(cfg, activation_checkpoint=args.activation_checkpoint)
+            model = MyGPT2LMHeadModel(cfg, activation_checkpoint=model_activation_checkpoint(args))
     return model.to(device=device, dtype=dtype), cfg
 
 

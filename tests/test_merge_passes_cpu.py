@@ -99,6 +99,29 @@ def test_auto_keeps_the_loaders_micro_batches_without_a_gpu(capsys):
     assert "runs as given" in capsys.readouterr().out
 
 
+def test_auto_decisions_from_a_measured_footprint(monkeypatch, capsys):
+    """The decision logic with the allocator statistics replaced: 1 GiB per micro-batch. 12 GiB free fits the
+    whole window of 4 and twice its footprint (recomputation off); 6 GiB fits the window but not twice it;
+    3 GiB fits two micro-batches per pass."""
+    gib = 2 ** 30
+    for free, merge, relaxed in ((12 * gib, 4, True), (6 * gib, 4, False), (3 * gib, 2, False)):
+        tr, cfg = _trainer("auto", steps=3)
+        tr.relax_recompute = True
+        assert tr.model.transformer.activation_checkpoint == "selective"
+        monkeypatch.setattr(tr, "_free_bytes", lambda device, free=free: free)
+        monkeypatch.setattr(tr, "_allocated_now", lambda device: 0)
+        monkeypatch.setattr(tr, "_allocated_peak", lambda device: gib)
+        seen = []
+        step = tr.training_step
+        tr.training_step = lambda x, y, seen=seen, step=step: (seen.append(x.shape[0]), step(x, y))[1]
+        tr.train(SyntheticTokenLoader(2, 16, cfg.vocab_size, num_batches=40))
+        assert seen == [2] * 4 + [2 * merge] * (2 * 4 // merge), (free, seen)
+        assert (tr.model.transformer.activation_checkpoint == "none") == relaxed
+        out = capsys.readouterr().out
+        assert ("recomputation switched off" in out) == relaxed
+        assert f"pass(es) of {2 * merge} sequences" in out
+
+
 def test_checkpoint_position_and_resume_with_merged_passes(tmp_path):
     ck = str(tmp_path / "ck")
     straight, cfg = _trainer(4, steps=4, save_every=2, ckpt=ck)
@@ -149,7 +172,7 @@ def _distributed_merge(rank, world, wrapper):
     plain.train(SyntheticTokenLoader(2, 16, cfg.vocab_size, "cpu", seed=70 + rank))
     merged, _ = build(2)
     # the ranks agree on the smaller choice: rank 1 asks for 4, rank 0 for 2
-    assert merged._agree_merge(2 if rank == 0 else 4) == 2
+    assert merged._agree(2 if rank == 0 else 4, rank == 0) == (2, False)
     merged.train(SyntheticTokenLoader(2, 16, cfg.vocab_size, "cpu", seed=70 + rank))
     assert merged.batch_count == plain.batch_count == 12
     a, b = plain.model.state_dict(), merged.model.state_dict()

@@ -38,7 +38,8 @@ def main():
                       global_batch_size=args.global_batch_size, micro_batch_size=args.micro_batch_size,
                       log_every_n_steps=args.log_every, save_every_n_steps=args.save_every,
                       checkpoint_dir=args.checkpoint_dir, metrics_file=args.metrics_file,
-                      merge_micro_batches=cli.resolve_merge(args))
+                      merge_micro_batches=cli.resolve_merge(args),
+                      relax_recompute=args.activation_checkpoint == "auto")
     resume = cli.resolve_resume(args)
     if resume:
         trainer.load_checkpoint(resume)

@@ -94,7 +94,8 @@ def main():
                                  micro_batch_size=args.micro_batch_size, log_every_n_steps=args.log_every,
                                  save_every_n_steps=args.save_every, checkpoint_dir=args.checkpoint_dir,
                                  ddp_enabled=True, metrics_file=args.metrics_file,
-                                 merge_micro_batches=cli.resolve_merge(args))
+                                 merge_micro_batches=cli.resolve_merge(args),
+                                 relax_recompute=args.activation_checkpoint == "auto")
     resume = cli.resolve_resume(args)
     if resume:
         trainer.load_checkpoint(resume)
