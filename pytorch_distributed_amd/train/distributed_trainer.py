@@ -92,6 +92,14 @@ class DistributedTrainer(Trainer):
         votes = [struct.unpack("<qq", blob) for blob in c.exchange(struct.pack("<qq", int(merge), int(relax)))]
         return min(v[0] for v in votes), all(v[1] for v in votes)
 
+    def _after_first_changed_step(self) -> None:
+        """The merged passes met GEMM shapes that no rank had planned before wrapping; every rank timed the
+        library's candidates for itself inside that step. Adopt rank 0's choices everywhere, as the
+        planning pass before wrapping does (``plan_sync``): one pace for all ranks."""
+        if self.ddp_enabled and self.world_size > 1 and torch.cuda.is_available():
+            from ..parallel import plan_sync
+            plan_sync.sync_decisions()
+
     def _aggregate_loss(self, loss: float, device) -> float:
         """Mean of the ranks' window losses. Every rank calls this on logging steps."""
         if not self.ddp_enabled or self.world_size == 1:

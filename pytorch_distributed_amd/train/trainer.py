@@ -83,6 +83,7 @@ class Trainer:
         self._merged_now = 1         # ... in the pass that is running (smaller only when the loader ran out)
         self._merge_pending = False  # "auto": still to be decided after the first window
         self._pass_bytes = None      # what the first pass allocated above the resident state
+        self._shapes_changed = False # set by the decision, cleared after the first step that ran with it
 
         if global_batch_size % micro_batch_size != 0:
             raise ValueError(f"Global batch size ({global_batch_size}) must be divisible by "
@@ -165,6 +166,9 @@ class Trainer:
     def _allocated_peak(device) -> int:
         return torch.cuda.max_memory_allocated(device)
 
+    def _after_first_changed_step(self) -> None:
+        """Hook: the first step with merged passes (new GEMM shapes, each planned where it was met) is done."""
+
     def _recompute_owner(self):
         """The module whose ``activation_checkpoint`` attribute sets the model's policy, or None."""
         owner = getattr(unwrap_model(self.model), "transformer", None)
@@ -189,6 +193,7 @@ class Trainer:
             relax = (self.relax_recompute and owner is not None and owner.activation_checkpoint == "selective"
                      and merge * self._pass_bytes * 1.1 * 2.0 <= room)
         merge, relax = self._agree(merge, relax)
+        self._shapes_changed = merge != self._merge or relax  # the next step meets GEMM shapes it has not planned
         self._merge = merge
         if relax:
             self._recompute_owner().activation_checkpoint = "none"
@@ -392,6 +397,9 @@ class Trainer:
                 self.loss_accumulator.zero_()
                 self.current_step += 1
                 self._maybe_checkpoint()
+                if self._shapes_changed:
+                    self._shapes_changed = False
+                    self._after_first_changed_step()
                 if tune_pending:
                     tune_pending = False
                     self._decide_merge(device)
