@@ -115,6 +115,20 @@ __device__ __forceinline__ const bf16_raw* stage_src(const bf16_raw* base, int64
   return base + int64_t(row0 + row) * ld + col;
 }
 
+// The same address in two parts, for the four-wave kernel: a wave-uniform element offset (rows of this
+// wave's role) and a per-lane BYTE offset that fits 32 bits. A load whose address is "scalar base +
+// zero-extended 32-bit lane offset" is issued in the scalar-base form of global_load_lds: its per-stage
+// address update is scalar arithmetic only, no vector instruction next to the MFMAs.
+__device__ __forceinline__ int64_t stage_src_uniform(int64_t ld, int row0, int wave) {
+  return int64_t(row0 + 2 * wave) * ld;
+}
+__device__ __forceinline__ unsigned stage_src_lane(int64_t ld, int col0, int cols, int wave, int lane) {
+  const int row = 2 * wave + (lane >> 5);
+  const int chunk = (lane & 31) ^ ((row & 3) << 2);
+  const int col = min(col0 + chunk * 8, cols - 8);
+  return unsigned((int64_t(lane >> 5) * ld + col) * int64_t(sizeof(bf16_raw)));
+}
+
 __device__ __forceinline__ void stage_half(const bf16_raw* src, char* tile, int half, int wave) {
   typedef __attribute__((address_space(1))) const void gptr_t;
   typedef __attribute__((address_space(3))) void lptr_t;
@@ -432,8 +446,19 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
   // The four roles of a wave differ by 8 q + 16 half rows, a multiple of 4: the swizzle (row & 3) and
   // with it the per-lane column are the same for all of them, so ONE per-lane pointer per operand
   // serves every load and the rest of the address is wave-uniform.
-  const bf16_raw* a_src = stage_src(A, lda, kSegmented ? 0 : step_lo * kBM, ti * kTile, I, 0, wave, lane);
-  const bf16_raw* b_src = stage_src(B, ldb, kSegmented ? 0 : step_lo * kBM, tj * kTile, J, 0, wave, lane);
+  const bf16_raw* a_uni = A + stage_src_uniform(lda, kSegmented ? 0 : step_lo * kBM, wave);  // wave-uniform
+  const bf16_raw* b_uni = B + stage_src_uniform(ldb, kSegmented ? 0 : step_lo * kBM, wave);
+  const unsigned a_lane = stage_src_lane(lda, ti * kTile, I, wave, lane);  // bytes, per lane, loop-invariant
+  const unsigned b_lane = stage_src_lane(ldb, tj * kTile, J, wave, lane);
+  // The loads are written in the scalar-base form by hand (left to the compiler, "uniform + lane" is folded
+  // back into one 64-bit vector add per load, next to the MFMAs). M0, the LDS destination, is written and
+  // read inside the one statement, one wait state apart as the LDS-DMA read of M0 requires.
+  // Stamps of the c_fc gradient at 65,536 rows: k-step 0 block 640 -> 627 ticks, kernel 873-878 -> 809-857 us.
+  auto load_to_lds = [&](const bf16_raw* uniform, unsigned lane_bytes, char* tile, int half, int role) {
+    const unsigned dst = lds_addr(tile + (16 * half + 2 * role) * kRowBytes);  // wave-uniform
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_bytes), "s"(uniform), "s"(dst) : "memory");  // M0 is reserved: the compiler rewrites it before every use of its own
+  };
   const int64_t a_stride = int64_t(kBM) * lda, b_stride = int64_t(kBM) * ldb;
   // Segmented operands: wave-uniform element differences of pieces 1..3 against piece 0.
   // (Locals, so that no lambda below captures the argument struct itself: a captured struct has its
@@ -461,18 +486,18 @@ __global__ __launch_bounds__(kThreads4) void wgrad_kernel4(const bf16_raw* __res
         const int64_t d1 = b_d1, d2 = b_d2, d3 = b_d3;
         const int64_t d_hi = lo ? d3 : d2, d_lo = lo ? d1 : int64_t(0);
         const int64_t d = hi ? d_hi : d_lo;
-        stage_half(b_src + d + rows * ldb, slot + kTileBytes, half, wave + 4 * q);
+        load_to_lds(b_uni + d + rows * ldb, b_lane, slot + kTileBytes, half, wave + 4 * q);
       } else {
         const int64_t d1 = a_d1, d2 = a_d2, d3 = a_d3;
         const int64_t d_hi = lo ? d3 : d2, d_lo = lo ? d1 : int64_t(0);
         const int64_t d = hi ? d_hi : d_lo;
-        stage_half(a_src + d + rows * lda, slot, half, wave + 4 * q);
+        load_to_lds(a_uni + d + rows * lda, a_lane, slot, half, wave + 4 * q);
       }
       return;
     }
     const int64_t rows = int64_t(t < n_steps ? t : n_steps - 1) * kBM + 16 * half + 8 * q;  // wave-uniform
-    if (is_b) stage_half(b_src + rows * ldb, slot + kTileBytes, half, wave + 4 * q);
-    else stage_half(a_src + rows * lda, slot, half, wave + 4 * q);
+    if (is_b) load_to_lds(b_uni + rows * ldb, b_lane, slot + kTileBytes, half, wave + 4 * q);
+    else load_to_lds(a_uni + rows * lda, a_lane, slot, half, wave + 4 * q);
   };
   // Every stage issues exactly 8 loads per wave — past the end of the slice they re-fetch its last
   // rows into a slot nobody reads any more — so the counted waits are the same in every iteration
