@@ -18,6 +18,7 @@
 //   broadcast       root sends to every peer
 //
 // Collectives are synchronous: they have completed when the call returns.
+#include <cstdlib>
 #include "communicator.h"
 #include "store.h"
 
@@ -81,6 +82,8 @@ void reduce_into(at::ScalarType t, void* dst, const std::vector<const void*>& sr
   }
 }
 
+constexpr int32_t kMeshMagic = 0x4D414450;  // "PDAM": first word of a peer's greeting on the mesh
+
 class SocketCommunicator final : public Communicator {
  public:
   SocketCommunicator(std::shared_ptr<Rendezvous> rv, double timeout_s) : rv_(std::move(rv)), timeout_s_(timeout_s) {
@@ -103,22 +106,46 @@ class SocketCommunicator final : public Communicator {
     for (int p = 0; p < rank_; ++p) {  // connect downwards
       const std::string addr = rv_->client->get(base + std::to_string(p));
       const size_t colon = addr.rfind(':');
+      if (const char* inject = std::getenv("PDA_SOCKET_MESH_STRANGER")) {  // fault injection for the test of the
+        if (inject[0] == '1') {                                             // accept loop: a foreign client first
+          int stray = net::connect_to(addr.substr(0, colon), std::stoi(addr.substr(colon + 1)), timeout_s_);
+          if (stray >= 0) {
+            const char foreign[12] = {'P', 'D', 'A', 'S', 'T', 'O', 'R', '1', 3, 0, 0, 0};
+            net::send_all(stray, foreign, sizeof(foreign));
+            ::close(stray);
+          }
+        }
+      }
       int fd = net::connect_to(addr.substr(0, colon), std::stoi(addr.substr(colon + 1)), timeout_s_);
       TORCH_CHECK(fd >= 0, "socket communicator: cannot connect to rank ", p, " at ", addr);
-      int32_t me = rank_;
-      net::send_all(fd, &me, 4);
+      const int32_t hello[2] = {kMeshMagic, rank_};
+      net::send_all(fd, hello, sizeof(hello));
       peers_[p] = fd;
     }
-    for (int k = rank_ + 1; k < world_; ++k) {  // accept upwards (any order; the peer names itself)
+    for (int k = rank_ + 1; k < world_;) {  // accept upwards (any order; the peer names itself)
       pollfd pf{lfd, POLLIN, 0};
       TORCH_CHECK(::poll(&pf, 1, (int)(timeout_s_ * 1000)) > 0, "socket communicator: timed out waiting for higher ranks");
       int fd = ::accept(lfd, nullptr, nullptr);
       TORCH_CHECK(fd >= 0, "socket communicator: accept failed");
       net::set_nodelay(fd);
-      int32_t who = -1;
-      net::recv_all(fd, &who, 4, timeout_s_);
+      // The listening port is an ephemeral one, and a rendezvous-store client of this or another job that
+      // scans a port range for its server may land on it: whoever does not open with the mesh's own
+      // greeting is turned away and the wait goes on.
+      int32_t hello[2] = {0, -1};
+      bool greeted = false;
+      try {
+        net::recv_all(fd, hello, sizeof(hello), 5.0);
+        greeted = hello[0] == kMeshMagic;
+      } catch (const std::exception&) {
+      }
+      if (!greeted) {
+        ::close(fd);
+        continue;
+      }
+      const int32_t who = hello[1];
       TORCH_CHECK(who > rank_ && who < world_ && peers_[who] < 0, "socket communicator: unexpected peer ", who);
       peers_[who] = fd;
+      ++k;
     }
     ::close(lfd);
     rv_->barrier("sock-mesh");

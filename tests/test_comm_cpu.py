@@ -65,6 +65,14 @@ def test_socket_collectives(world):
     run_distributed(_collectives, world=world)
 
 
+def test_socket_mesh_turns_away_foreign_clients(monkeypatch):
+    """A rendezvous-store client that scans a port range for its server can land on a rank's mesh listener (an
+    ephemeral port). With the injection every higher rank first opens such a connection — the store's greeting,
+    then close — before its real one: the accept loop must turn it away and still build the mesh."""
+    monkeypatch.setenv("PDA_SOCKET_MESH_STRANGER", "1")
+    run_distributed(_collectives, world=3)
+
+
 def _c10d_adapter(rank, world):
     """The same wrappers over a torch.distributed gloo group behind the Communicator interface."""
     from pytorch_distributed_amd.parallel import DDP, get_communicator
