@@ -50,6 +50,12 @@ int main(int argc, char** argv) {
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     if (it >= 2) t.push_back(ms * 1e3f);
   }
+  // Bits of the result, so that two builds of the kernels can be compared (both kernels are deterministic).
+  std::vector<unsigned short> hd(n_qkv);
+  CHECK(hipMemcpy(hd.data(), dqkv, n_qkv * 2, hipMemcpyDeviceToHost));
+  unsigned long long sum = 0, mix = 0;
+  for (int64_t i = 0; i < n_qkv; ++i) { sum += hd[i]; mix = mix * 1099511628211ull + hd[i]; }
+  printf("result checksum: sum %llu mix %016llx\n", sum, mix);
   std::sort(t.begin(), t.end());
   printf("B %d H %d T %d D %d: backward (dQ + dK/dV) median %.1f us, min %.1f us\n", B, H, T, D, t[t.size() / 2], t[0]);
   return 0;
