@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -86,3 +88,39 @@ def test_analyze_traces_draws_the_notebook_figures(tmp_path):
     # 100 us of communication (150..250), 30 + 50 of it under the two compute kernels it spans -> 80 % overlap
     row = [ln for ln in out.stdout.splitlines() if ln.startswith("ddp")][0].split()
     assert abs(float(row[-1]) - 80.0) < 0.5, row
+
+
+def test_trace_notebook_cells_run_on_the_stored_traces(tmp_path, capsys):
+    """analyze_traces.ipynb (the notebook form of analyze_traces.py): its code cells run as they stand on the
+    per-rank traces kept under profiles/r3/traces — table, figures, kernel differences. IPython's display is
+    replaced, since no notebook front end runs here."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traces = os.path.join(root, "profiles", "r3", "traces")
+    if not os.path.isdir(os.path.join(traces, "ddp")):
+        pytest.skip("stored traces not present")
+    nb = json.load(open(os.path.join(root, "analyze_traces.ipynb")))
+    assert nb["nbformat"] == 4
+    shown, env = [], {"__name__": "notebook"}
+    cwd = os.getcwd()
+    os.chdir(root)
+    sys.path.insert(0, root)
+    try:
+        for cell in nb["cells"]:
+            if cell["cell_type"] != "code":
+                continue
+            src = "".join(cell["source"])
+            src = src.replace('TRACES = "outputs/traces"', f"TRACES = {traces!r}")
+            src = src.replace('"outputs/plots"', repr(str(tmp_path / "plots")))
+            src = src.replace("from IPython.display import Image, display",
+                              "Image = lambda filename: filename\ndisplay = shown.append")
+            env["shown"] = shown
+            exec(compile(src, "analyze_traces.ipynb", "exec"), env)
+    finally:
+        sys.path.remove(root)
+        os.chdir(cwd)
+    out = capsys.readouterr().out
+    assert "fsdp_full_shard" in out and "=== baseline -> ddp" in out
+    assert [os.path.basename(p) for p in shown] == ["temporal_breakdown.png", "comm_comp_overlap.png"]
+    assert all(os.path.getsize(p) > 10_000 for p in shown)
