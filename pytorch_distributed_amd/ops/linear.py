@@ -302,7 +302,9 @@ def weight_grads(dy2, x2, weight, bias, grad_sink, bias_sink, need_w: bool, need
             dy2 = dy2.contiguous()
         x2 = x2.contiguous()
         pairs = None
-        if _ACTIVE:
+        # Kept operands are filed under the weight's identity, so only a leaf parameter takes part: a derived
+        # tensor (the bf16 copy of an fp32 weight, made anew in every forward) would never be found again.
+        if _ACTIVE and weight.is_leaf:
             if _WINDOW.index < _WINDOW.total - 1:
                 if _keep_for_later(dy2, x2, weight):
                     return None, None  # autograd's accumulator nodes still run (see above)

@@ -190,3 +190,21 @@ def test_gradient_sinks_receive_the_window_in_one_write(fake):
     assert asked == [0]
     assert layers[0].weight.grad is None  # written into the sink, None handed to autograd
     assert torch.allclose(flat.view(16, 24), _reference(4)[0][0], atol=1e-4)
+
+
+def test_a_derived_weight_is_never_kept(fake):
+    """fp32 storage runs every product on a bf16 COPY of the weight made anew in each forward: such a tensor has
+    no identity to file kept operands under, so its products are formed per micro-batch (and nothing is left
+    behind for the window's end to complain about); the leaf parameter next to it is still deferred."""
+    n = 3
+    layers = _layers()
+    xs, gs = _data(n)
+    for i, (x, g) in enumerate(zip(xs, gs)):
+        with ops.accumulation_window(i, n):
+            h = L._LinearFn.apply(x, layers[0].weight * 1.0, layers[0].bias * 1.0, None)  # derived: not a leaf
+            h = L._LinearFn.apply(h, layers[1].weight, layers[1].bias, None)
+            h.backward(g)
+        assert ops.pending_weight_grads() == (1 if i < n - 1 else 0)
+    assert sorted(c[0] for c in fake.calls) == ["one"] * n + ["segments"]
+    for lin, (rw, rb) in zip(layers, _reference(n)):
+        assert torch.allclose(lin.weight.grad, rw, atol=1e-4) and torch.allclose(lin.bias.grad, rb, atol=1e-4)

@@ -358,3 +358,24 @@ def test_deferred_weight_gradients_are_closer_to_fp32_than_bf16_accumulation(mon
     with linear_ops.accumulation_window(0, 2):
         pass
     assert linear_ops.pending_weight_grads() == 0
+
+
+def test_fp32_storage_accumulates_through_a_window():
+    """``--dtype fp32`` on the GPU: every product runs on a bf16 copy of the fp32 weight that is made anew in each
+    forward. Such copies are never filed in the window (they could not be found again); the window closes
+    without complaint and the fp32 gradients are the sum over the micro-batches."""
+    from pytorch_distributed_amd import ops
+
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 128, device=DEV, dtype=torch.float32)
+    xs = [torch.randn(2, 64, 256, device=DEV) for _ in range(3)]
+    gs = [torch.randn(2, 64, 128, device=DEV) for _ in range(3)]
+    for i, (x, g) in enumerate(zip(xs, gs)):
+        with ops.accumulation_window(i, 3):
+            ops.linear(x, lin.weight, lin.bias).backward(g)
+        assert ops.pending_weight_grads() == 0
+    exact_w = sum(g.flatten(0, 1).t() @ x.flatten(0, 1) for g, x in zip(gs, xs))
+    exact_b = sum(g.flatten(0, 1).sum(0) for g in gs)
+    assert lin.weight.grad.dtype == torch.float32
+    assert ((lin.weight.grad - exact_w).norm() / exact_w.norm()).item() < 1e-2   # bf16 operands, fp32 sums
+    assert ((lin.bias.grad - exact_b).norm() / exact_b.norm()).item() < 1e-2
