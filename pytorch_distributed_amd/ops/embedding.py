@@ -34,7 +34,7 @@ def _grad_target(param, sink):
     if wide is not None and wide != param.dtype:
         sink = None
     target = sink() if sink is not None else None
-    if target is None and param.grad is not None and param.grad.is_contiguous():
+    if target is None and param.is_leaf and param.grad is not None and param.grad.is_contiguous():
         target = (param.grad, True)
     return target
 

@@ -172,7 +172,9 @@ def _grad_target(param, sink, wide_ok: bool = True):
     if sink is not None and not wide_ok and sink_is_wide(param):
         sink = None
     target = sink() if sink is not None else None
-    if target is None and param.grad is not None and param.grad.is_contiguous():
+    # (only a leaf has a .grad of its own: a derived tensor, e.g. the bf16 copy of an fp32 weight, gets a
+    # fresh gradient that autograd carries on to its source)
+    if target is None and param.is_leaf and param.grad is not None and param.grad.is_contiguous():
         target = (param.grad, True)
     return target
 
