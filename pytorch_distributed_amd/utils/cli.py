@@ -119,9 +119,9 @@ def build_optimizer(args, params):
     return opt, sched
 
 
-def train_files(args) -> List[str]:
-    if args.make_synthetic_shards:
-        files = make_synthetic_fineweb_files(args.data_dir, args.num_train_files)
+def train_files(args, vocab_size: int = 50257) -> List[str]:
+    if args.make_synthetic_shards:  # token ids the model's embedding can look up
+        files = make_synthetic_fineweb_files(args.data_dir, args.num_train_files, vocab_size=vocab_size)
     else:
         files = download_fineweb10B_files(args.data_dir, num_train_files=args.num_train_files)
     return [str(f) for f in files if "train" in str(f)]
@@ -131,7 +131,7 @@ def build_loader(args, cfg, device, distributed: bool, rank: int = 0):
     if args.synthetic_data:
         return SyntheticTokenLoader(args.micro_batch_size, args.sequence_length, cfg.vocab_size, device,
                                     seed=1234 + rank)
-    files = train_files(args)
+    files = train_files(args, cfg.vocab_size)
     if distributed:
         return DistributedKJJ0DataLoader(files, args.micro_batch_size, args.sequence_length, device,
                                          prefetch=getattr(args, "prefetch_data", False))
