@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the round-3 numbers quoted in profiles/README.md into gpurun_out/r3_final (run on the GPU box).
+# Collects the numbers quoted in profiles/README.md (tables of `r3_final/`) into gpurun_out/r3_final (run on the GPU box).
 # Every GPU step runs under its own time limit and the script stops at the first failure.
 set -o pipefail
 export TMPDIR=/tmp MASTER_ADDR=127.0.0.1

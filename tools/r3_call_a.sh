@@ -1,5 +1,5 @@
 #!/bin/bash
-# First GPU call of round 3 (run from the repo root on the GPU box): GPU tests, the in-process kernel
+# GPU call (run from the repo root on the GPU box): GPU tests, the in-process kernel
 # tracer through the plain training commands, then the two benchmark lines. Every GPU step runs
 # under its own time limit; a step that ends by signal / abort / time-out ends the script.
 set -o pipefail

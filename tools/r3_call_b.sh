@@ -1,5 +1,5 @@
 #!/bin/bash
-# Second GPU call of round 3: GPU tests again (new tests), the plain-command traces, kernel breakdown
+# GPU call: GPU tests again (new tests), the plain-command traces, kernel breakdown
 # of the reference's recipe (4 micro-batches of 8, selective) next to the default step, Llama-7B FSDP.
 set -o pipefail
 export TMPDIR=/tmp MASTER_ADDR=127.0.0.1

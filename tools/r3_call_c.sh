@@ -1,5 +1,5 @@
 #!/bin/bash
-# Third GPU call of round 3: GPU tests (segmented weight-gradient kernel, deferred weight gradients,
+# GPU call: GPU tests (segmented weight-gradient kernel, deferred weight gradients,
 # cached AdamW lists), then A/B of the reference's recipe (4 micro-batches of 8, selective) with the
 # weight gradients formed per micro-batch and once per window, and its kernel breakdown.
 set -o pipefail
