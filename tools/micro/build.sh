@@ -10,3 +10,4 @@ hipcc --offload-arch=gfx950 -O3 -I pytorch_distributed_amd/csrc/kernels -o tools
 for p in attn_stamp attn_bwd_time; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pytorch_distributed_amd/csrc/kernels -I pytorch_distributed_amd/csrc -o tools/micro/bin/$p tools/micro/$p.hip
 done
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pytorch_distributed_amd/csrc/kernels -o tools/micro/bin/quad_transpose_check tools/micro/quad_transpose_check.hip
