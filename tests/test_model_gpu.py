@@ -1,5 +1,6 @@
 """End-to-end parity on the GPU: the HIP-kernel model against the same model on the PyTorch
 reference ops (fp32), plus a short training run."""
+import gc
 import os
 
 import pytest
@@ -160,11 +161,17 @@ def test_selective_policy_is_bit_identical_and_keeps_less_memory():
     torch.manual_seed(3)
     base = MyGPT2LMHeadModel(cfg, activation_checkpoint="none").to(device=DEV, dtype=torch.bfloat16)
     ids = torch.randint(0, cfg.vocab_size, (8, 513), device=DEV)
+    # One step beforehand: whatever the runtime allocates once and keeps (the GEMM planner's 64 MiB workspace, taken
+    # the first time a chosen algorithm asks for one — which GEMM that is depends on the box's timings) must not be
+    # counted as the first mode's activations.
+    base(ids[:, :-1], ids[:, 1:]).backward()
+    base.zero_grad(set_to_none=True)
     results, peaks = {}, {}
     for mode in ("none", "selective", "full"):
         model = MyGPT2LMHeadModel(cfg, activation_checkpoint=mode).to(device=DEV, dtype=torch.bfloat16)
         model.load_state_dict(base.state_dict())
         model.train()
+        gc.collect()  # garbage of earlier tests (autograd graphs, captured graphs) must not be freed mid-measurement
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         before = torch.cuda.memory_allocated()
