@@ -181,13 +181,14 @@ def _grad_target(param, sink, wide_ok: bool = True):
 
 class _Window:
     """State of the gradient-accumulation window whose backward passes are running."""
-    __slots__ = ("index", "total", "kept", "kept_bytes", "budget", "transposed")
+    __slots__ = ("index", "total", "kept", "kept_bytes", "budget", "measured_budget", "transposed")
 
     def __init__(self):
         self.index, self.total = 0, 1
         self.kept: dict = {}  # id(weight) -> (weight, [(dy2, x2), ...])
         self.kept_bytes = 0   # of the micro-batch `index`
         self.budget = None    # bytes one micro-batch may keep; measured at the window's first keep
+        self.measured_budget = None  # the last measurement (reused while a HIP graph is being captured)
         self.transposed: dict = {}  # (id(weight), row padding) -> (weight, transposed copy) for the input-gradient GEMMs
 
     def clear(self):
@@ -252,9 +253,14 @@ def _keep_for_later(dy2, x2, weight) -> bool:
     """Keeps one (dY, X) pair for the window's last backward; False when the budget is used up."""
     w = _WINDOW
     if w.budget is None:
-        # Measured where a backward starts, i.e. at the activation peak: what is free now is what the
-        # later micro-batches' kept operands can grow into.
-        w.budget = int(0.8 * _free_bytes(dy2.device)) // max(1, w.total - 1)
+        if w.measured_budget is not None and dy2.is_cuda and torch.cuda.is_current_stream_capturing():
+            # no queries of the driver while a graph is being recorded: the warm-up steps before the capture
+            # measured the same window
+            w.budget = w.measured_budget
+        else:
+            # Measured where a backward starts, i.e. at the activation peak: what is free now is what the
+            # later micro-batches' kept operands can grow into.
+            w.budget = w.measured_budget = int(0.8 * _free_bytes(dy2.device)) // max(1, w.total - 1)
     size = dy2.numel() * dy2.element_size() + x2.numel() * x2.element_size()
     if w.kept_bytes + size > w.budget:
         return False

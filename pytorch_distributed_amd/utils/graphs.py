@@ -55,10 +55,13 @@ class GraphedTrainStep:
                                      "Set every dropout probability to 0 (config.without_dropout()).")
 
     def _eager_step(self) -> None:
+        from .. import ops
         total = None
         for i in range(self.accum):
-            loss = self.model(self._inputs[i], self._targets[i]) / self.accum
-            loss.backward()
+            # the window's weight gradients are formed once, from the kept operands, inside the graph as outside it
+            with ops.accumulation_window(i, self.accum):
+                loss = self.model(self._inputs[i], self._targets[i]) / self.accum
+                loss.backward()
             total = loss.detach().float() if total is None else total + loss.detach().float()
         self.optimizer.step(zero_grad=True)
         self._loss.copy_(total)
