@@ -278,3 +278,42 @@ def test_llama_gradients_over_an_accumulation_window_match_per_micro_batch_produ
     assert d.keys() == p.keys()
     for n in p:
         assert rel_err(d[n], p[n]) < 2e-2, n
+
+
+@pytest.mark.parametrize("arch", ["gpt2", "llama"])
+def test_sizes_off_the_kernels_tiles_match_the_reference_ops(arch, monkeypatch):
+    """Batch sizes and sequence lengths that are no multiples of any kernel's tile (attention 64 / 128 rows, the
+    weight-gradient kernel's 32-row stages, 16-byte vectors of the streaming kernels): loss and every gradient of
+    the HIP path against the PyTorch reference ops of the same bf16 model."""
+    from pytorch_distributed_amd.models import LlamaForCausalLM
+
+    torch.manual_seed(0)
+    if arch == "gpt2":
+        cfg = get_config("gpt2", n_layer=2).without_dropout()
+        model = MyGPT2LMHeadModel(cfg, activation_checkpoint="selective")
+    else:
+        cfg = get_config("llama-tiny", n_layer=2, n_embd=256, n_head=2, intermediate_size=704, vocab_size=1000,
+                         n_ctx=1100).without_dropout()
+        model = LlamaForCausalLM(cfg, activation_checkpoint="selective")
+    model = model.to(device=DEV, dtype=torch.bfloat16).train()
+
+    def run(ids, reference):
+        if reference:
+            monkeypatch.setenv("PDA_FORCE_REFERENCE", "1")
+        else:
+            monkeypatch.delenv("PDA_FORCE_REFERENCE", raising=False)
+        for p in model.parameters():
+            p.grad = None
+        loss = model(ids[:, :-1].contiguous(), ids[:, 1:].contiguous())
+        loss.backward()
+        monkeypatch.delenv("PDA_FORCE_REFERENCE", raising=False)
+        return loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters()}
+
+    for B, T in ((1, 17), (3, 100), (2, 1000), (7, 33)):
+        ids = torch.randint(0, cfg.vocab_size, (B, T + 1), device=DEV)
+        l_hip, g_hip = run(ids, False)
+        l_ref, g_ref = run(ids, True)
+        assert abs(l_hip - l_ref) < 3e-2, (B, T, l_hip, l_ref)
+        for n in g_ref:
+            rel = ((g_hip[n] - g_ref[n]).norm() / (g_ref[n].norm() + 1e-6)).item()
+            assert rel < 5e-2, (B, T, n, rel)
